@@ -1,0 +1,92 @@
+"""ctypes binding of include/fjsp_amd.h (libfjsp_amd.so).
+
+The library is the product: if it is missing or a symbol is absent this module
+raises -- there is no Python/CPU fallback for the accelerated path.
+"""
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+_lib = None
+
+# name -> (restype, argtypes); keep in step with include/fjsp_amd.h
+_vp, _i32, _i64, _u64, _dbl, _cp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_char_p
+_pp = C.POINTER(C.c_void_p)
+
+
+class GenParams(C.Structure):
+    """fjsp_gen_params (Instance_generate.py:39-66 distributions)."""
+    _fields_ = [("R_min", _i32), ("R_max", _i32), ("J_min", _i32), ("J_max", _i32), ("M", _i32),
+                ("p_min", _i32), ("p_max", _i32), ("N_min", _i32), ("N_max", _i32), ("S", _i32),
+                ("DDT", _dbl), ("t_si_min", _dbl), ("t_si_max", _dbl)]
+
+
+SIGNATURES = {
+    "fjsp_last_error": (_cp, []),
+    "fjsp_abi_version": (C.c_int, []),
+    "fjsp_instances_create": (C.c_int, [_i32, _pp]),
+    "fjsp_instances_destroy": (None, [_vp]),
+    "fjsp_instances_count": (C.c_int, [_vp]),
+    "fjsp_instances_load_csv": (C.c_int, [_vp, _i32, _cp, _cp]),
+    "fjsp_instances_generate": (C.c_int, [_vp, _i32, _u64, C.POINTER(GenParams)]),
+    "fjsp_instances_set_raw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl]),
+    "fjsp_instances_dims": (C.c_int, [_vp, _i32, C.POINTER(_i32 * 6)]),
+    "fjsp_instances_get": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_dbl), _vp]),
+    "fjsp_instances_solve_fluid": (C.c_int, [_vp, _i32, _i32, _i32]),
+    "fjsp_instances_set_x": (C.c_int, [_vp, _i32, _vp]),
+    "fjsp_fluid_lp": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_dbl)]),
+    "fjsp_env_create": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _u64, _pp]),
+    "fjsp_env_destroy": (None, [_vp]),
+    "fjsp_env_num_envs": (C.c_int, [_vp]),
+    "fjsp_env_state_size": (C.c_int, [_vp]),
+    "fjsp_env_device": (C.c_int, [_vp]),
+    "fjsp_env_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "fjsp_env_step": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "fjsp_env_rollout": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "fjsp_env_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_env_machine_time_end": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "fjsp_env_fluid_tables": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "fjsp_env_step_bytes": (_i64, [_vp]),
+    "fjsp_rollout_create": (C.c_int, [_i32, _i32, _i32, _i32, _pp]),
+    "fjsp_rollout_destroy": (None, [_vp]),
+    "fjsp_rollout_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_rollout_returns": (C.c_int, [_vp, _dbl, _vp]),
+    "fjsp_rollout_clear": (C.c_int, [_vp]),
+    "fjsp_rollout_len": (C.c_int, [_vp]),
+    "fjsp_rollout_ptr": (_vp, [_vp, _i32]),
+}
+
+
+class FjspError(RuntimeError):
+    """A C-ABI call returned a negative FJSP_E_* code."""
+
+    def __init__(self, code, message):
+        super().__init__("libfjsp_amd error %d: %s" % (code, message))
+        self.code = code
+
+
+def lib():
+    """Load libfjsp_amd.so (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP extension is the product and there is no fallback. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repo root." % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if handle.fjsp_abi_version() != 1:
+        raise ImportError("libfjsp_amd.so ABI version mismatch")
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise FjspError(rc, lib().fjsp_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,196 @@
+/*
+ * include/fjsp_amd.h -- C ABI of libfjsp_amd.so (MI355X / gfx950).
+ *
+ * The reference (Linshan-Ding/Deep_Reinforcement_Learning_for_FJSP) has no FFI:
+ * its boundary is the duck-typed Python protocol  Env(...).reset() / .step(a)
+ * plus a handful of attributes.  This header is what a
+ * binding for that protocol binds to; each entry point cites the reference
+ * function it replaces (paths relative to the reference root).  Plain pointers
+ * and sizes only -- no torch / HIP types in the signatures (streams are passed
+ * as void*, i.e. a hipStream_t; NULL = the default stream).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FJSP_E_* code;
+ *     fjsp_last_error() returns a thread-local message for the last failure;
+ *   - "h_" pointers are host memory, "d_" pointers are device (HBM) memory
+ *     owned by the caller unless stated otherwise;
+ *   - k = koff[r] + j is the r-major operation-type index (kind_task_tuple
+ *     order, environments/SO_DFJSP_instance_read.py:25);
+ *   - the device entry points are asynchronous on the given stream and never
+ *     synchronise; per-env errors are reported in the status array
+ *     (fjsp_env_status), not by aborting the batch.
+ */
+#ifndef FJSP_AMD_H
+#define FJSP_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FJSP_ABI_VERSION 1
+
+enum {
+    FJSP_OK = 0,
+    FJSP_E_ARG = -1,        /* bad argument                                            */
+    FJSP_E_IO = -2,         /* file missing / unparsable                               */
+    FJSP_E_FORMAT = -3,     /* instance violates a format assumption                   */
+    FJSP_E_LP = -4,         /* fluid LP failed                                         */
+    FJSP_E_UNSUPPORTED = -5,/* instance outside what the kernels handle (K, M, jobs)   */
+    FJSP_E_HIP = -6,        /* HIP runtime error (no device, launch failure, ...)      */
+    FJSP_E_STATE = -7       /* call order violated (e.g. fluid solution missing)       */
+};
+
+/* per-env status bits written by the kernels (fjsp_env_status) */
+enum {
+    FJSP_ST_BAD_TASK_RULE = 1,    /* MyError, SO_FJSSP.py:297                          */
+    FJSP_ST_BAD_MACHINE_RULE = 2, /* MyError, SO_FJSSP.py:321                          */
+    FJSP_ST_STEP_AFTER_DONE = 4,  /* reference: undefined (ValueError on max([]))      */
+    FJSP_ST_NO_EVENT = 8          /* reference: ValueError min([]) at SO_FJSSP.py:207  */
+};
+
+/* environment variants sharing the SO_FJSSP skeleton */
+enum {
+    FJSP_VARIANT_SO_FJSSP = 0,          /* environments/SO_FJSSP.py (pair action [6,5], 20-dim state) */
+    FJSP_VARIANT_MO_FJSSP_DISCRETES = 2 /* environments/MO_FJSSP_discretes.py (flat 18, 25-dim state)  */
+};
+
+const char *fjsp_last_error(void);
+int fjsp_abi_version(void);
+
+/* ------------------------------------------------------------------------- *
+ * Host side: instance sets (replaces Data / Instance / FJSP.__init__ / fluid_model)
+ * ------------------------------------------------------------------------- */
+typedef struct fjsp_instances fjsp_instances;
+
+/* Parameters of the synthetic generator (environments/Instance_generate.py:19-94).
+ * The reference generator is unseeded; this one is a counter-based splitmix64
+ * stream so instance i of a batch is a pure function of (seed, params). */
+typedef struct {
+    int32_t R_min, R_max;     /* kinds                     (:42  U{3..12})            */
+    int32_t J_min, J_max;     /* ops per kind              (:46  U{3..5})             */
+    int32_t M;                /* machines                  (constructor argument)     */
+    int32_t p_min, p_max;     /* processing time           (:50  U{40..400})          */
+    int32_t N_min, N_max;     /* jobs per kind per order   (:54  U{5..50})            */
+    int32_t S;                /* orders                    (constructor argument)     */
+    double  DDT;              /* due-date tightness        (constructor argument)     */
+    double  t_si_min, t_si_max; /* order inter-arrival     (:58  U(100,200))          */
+} fjsp_gen_params;
+
+int  fjsp_instances_create(int32_t n, fjsp_instances **out);
+void fjsp_instances_destroy(fjsp_instances *s);
+int  fjsp_instances_count(const fjsp_instances *s);
+
+/* Data(path, file_name): environments/SO_DFJSP_instance_read.py:6-89
+ * (based_data.csv / process_data.csv / order_data.csv; numbers via the
+ * reference's `\d+` extraction, so DDT "0.5" parses to 0). */
+int fjsp_instances_load_csv(fjsp_instances *s, int32_t i, const char *path, const char *file_name);
+/* Instance(DDT, M, S): environments/Instance_generate.py:24-94, seeded. */
+int fjsp_instances_generate(fjsp_instances *s, int32_t i, uint64_t seed, const fjsp_gen_params *prm);
+/* Raw arrays (same meaning as the fjsp_instances_get outputs). */
+int fjsp_instances_set_raw(fjsp_instances *s, int32_t i, int32_t R, int32_t M, int32_t S,
+                           const int32_t *Jr, const int32_t *p /*[K*M] k-major, 0 = ineligible*/,
+                           const int32_t *elig_n /*[K]*/, const int32_t *elig_list /*[K*M] file order*/,
+                           const int32_t *count /*[S*R]*/, const int32_t *arrive /*[S]*/,
+                           const int32_t *delivery /*[S]*/, double ddt);
+/* dims[0..5] = R, M, K, S, jobs of order 0, total jobs over all orders */
+int fjsp_instances_dims(const fjsp_instances *s, int32_t i, int32_t dims[6]);
+/* Any output pointer may be NULL. */
+int fjsp_instances_get(const fjsp_instances *s, int32_t i, int32_t *Jr, int32_t *p, int32_t *elig_n,
+                       int32_t *elig_list, int32_t *count, int32_t *arrive, int32_t *delivery,
+                       double *ddt, double *x /*[K*M] k-major, fluid solution or zeros*/);
+
+/* FJSP.fluid_model() for the reset-time state (environments/class_FJSSP.py:246-280):
+ * solves the fluid LP of instances [first, first+n) with the library's own
+ * deterministic vertex simplex on n_threads host threads and stores x. */
+int fjsp_instances_solve_fluid(fjsp_instances *s, int32_t first, int32_t n, int32_t n_threads);
+/* Override the stored fluid solution (x is an INPUT of the accelerated path). */
+int fjsp_instances_set_x(fjsp_instances *s, int32_t i, const double *x /*[K*M] k-major*/);
+/* One fluid LP for an arbitrary live state (class_FJSSP.py:246-280):
+ * Q[k] = fluid_unprocessed_number_start, n_now[k] = fluid_number. */
+int fjsp_fluid_lp(int32_t R, int32_t M, const int32_t *Jr, const int32_t *p /*[K*M]*/,
+                  const int32_t *Q /*[K]*/, const int32_t *n_now /*[K]*/,
+                  double *x /*[K*M]*/, double *objective);
+
+/* ------------------------------------------------------------------------- *
+ * Device side: a batch of N environments resident in HBM
+ * ------------------------------------------------------------------------- */
+typedef struct fjsp_env fjsp_env;
+
+/* FJSP.__init__ + SO_FJSSP_Environment.__init__ (class_FJSSP.py:151-171,
+ * SO_FJSSP.py:14-48) for N envs: env e uses instance (first + e % n_inst).
+ * Packs the padded struct-of-arrays, uploads it to `device`, and runs the
+ * fluid-table kernel (update_fluid_parameter, class_FJSSP.py:282-306). */
+int  fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int32_t n_envs,
+                     int32_t variant, int32_t device, uint64_t rng_seed, fjsp_env **out);
+void fjsp_env_destroy(fjsp_env *e);
+int  fjsp_env_num_envs(const fjsp_env *e);
+int  fjsp_env_state_size(const fjsp_env *e);   /* 20 (SO_FJSSP) / 25 (MO_FJSSP_discretes) */
+int  fjsp_env_device(const fjsp_env *e);
+
+/* reset(): SO_FJSSP.py:51-76.  d_mask (u8[N], nullable): reset only envs with
+ * mask != 0.  d_state (f64[N][state_size], nullable) receives the state. */
+int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *stream);
+
+/* step(action): SO_FJSSP.py:168-265.  d_actions u8[N][2] = (task rule, machine
+ * rule) indices as the reference's action pair (:171-172); for the MO variant
+ * d_actions[..][0] is the flat action and d_mo (f64[N][4] = w0, w1, completion,
+ * tardiness; <=0 = None; nullable) carries step()'s extra arguments
+ * (MO_FJSSP_discretes.py:88).  Outputs (all nullable): d_state f64[N][S],
+ * d_reward f64[N], d_done u8[N].  Envs already done are left untouched and get
+ * FJSP_ST_STEP_AFTER_DONE unless autoreset != 0, in which case a done env is
+ * reset first and the step applies to the fresh episode. */
+int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset,
+                  double *d_state, double *d_reward, uint8_t *d_done, void *stream);
+
+/* T fused steps in ONE launch (rule-sweep harnesses, MO_DFJSP.py:481-518 style):
+ * d_actions u8[T][N][2]; envs that finish early idle (no autoreset).
+ * Trace outputs (nullable): d_trace_km i16[T][N][2] = chosen (k, m) or -1,
+ * d_reward f64[T][N], d_state_last f64[N][S]. */
+int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, int32_t T, int16_t *d_trace_km,
+                     double *d_reward, double *d_state_last, void *stream);
+
+/* Read-back of the attributes agents / harnesses read, device
+ * pointers, any may be NULL: delay_time_sum i64[N], makespan = max machine
+ * time_end i32[N], completion_time i32[N], step_time i32[N], step_count i32[N],
+ * done u8[N], status u32[N] (FJSP_ST_* bits, sticky until reset). */
+int fjsp_env_read(fjsp_env *e, int64_t *d_delay_time_sum, int32_t *d_makespan, int32_t *d_completion,
+                  int32_t *d_step_time, int32_t *d_step_count, uint8_t *d_done, uint32_t *d_status,
+                  void *stream);
+/* machine_dict[m].time_end: i32[N][M_max] (SO_FJSSP.py:426). */
+int fjsp_env_machine_time_end(fjsp_env *e, int32_t *d_tend, int32_t m_stride, void *stream);
+/* fluid tables of env i copied to host (tests): rate/arr [K*M] k-major, rate_sum/time_sum [K]. */
+int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
+                          double *h_rate_sum, double *h_time_sum);
+/* HBM bytes the step kernel reads+writes per env-step (algorithmic). */
+int64_t fjsp_env_step_bytes(const fjsp_env *e);
+
+/* ------------------------------------------------------------------------- *
+ * Rollout buffer (on-policy Replay_Buffer, agents/MPPPO/Buffer.py:7-58) in HBM
+ * ------------------------------------------------------------------------- */
+typedef struct fjsp_rollout fjsp_rollout;
+
+/* Capacity T steps x N envs x state_size; storage f32 like Buffer.py:41-45. */
+int  fjsp_rollout_create(int32_t T, int32_t N, int32_t state_size, int32_t device, fjsp_rollout **out);
+void fjsp_rollout_destroy(fjsp_rollout *b);
+/* add_experience (Buffer.py:19-28): converts the f64 env outputs of one
+ * batched step to f32 rows at the write cursor t. `d_active` u8[N] (nullable)
+ * = envs that were not done before the step (valid-row mask). */
+int fjsp_rollout_append(fjsp_rollout *b, const double *d_state, const uint8_t *d_actions,
+                        const double *d_reward, const double *d_next_state, const uint8_t *d_done,
+                        const uint8_t *d_active, void *stream);
+/* calculate_discounted_returns (agents/MPPPO/MPPPO.py:301-312): reverse scan
+ * G_t = r_t + gamma * G_{t+1} per env over valid rows, f64 scan -> f32. */
+int fjsp_rollout_returns(fjsp_rollout *b, double gamma, void *stream);
+/* clear(): Buffer.py:53-55 */
+int fjsp_rollout_clear(fjsp_rollout *b);
+int fjsp_rollout_len(const fjsp_rollout *b);
+/* Device pointers into the buffer (wrapped zero-copy by the PyTorch side):
+ * which = 0 states f32[T][N][S], 1 actions f32[T][N][2], 2 rewards f32[T][N],
+ * 3 next_states f32[T][N][S], 4 dones f32[T][N], 5 valid f32[T][N], 6 returns f32[T][N]. */
+void *fjsp_rollout_ptr(fjsp_rollout *b, int32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

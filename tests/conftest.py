@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build (if stale) the product library and the oracle once per session."""
+    from deep_reinforcement_learning_for_fjsp_amd import _build
+    _build.build_library()
+    _build.build_oracle()
+    return True
