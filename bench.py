@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path named by BASELINE.json: batched SO_FJSSP env steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1], per GPU): 4096 generated 10-job x 5-machine
+SO_FJSSP instances (generator seeds 1000 + global env id, fluid LP solved on the
+host before the timed region), random policy from a pre-generated action tensor
+resident in HBM, ONE bench step = ONE launch of the per-step HIP kernel over all
+envs through the C ABI (fjsp_env_step, autoreset on, so every launch advances
+every env by exactly one environment step).
+
+Prints ONE JSON line (rank 0): metric env-steps/s (whole job), plus
+  roofline      the step kernel's algorithmic HBM bytes per launch / its mean launch
+                duration from HIP events, against the 8 TB/s HBM peak
+  cpu_baseline  the C oracle (a scalar CPU port of the reference) timed on one host
+                core on a bounded sample of the same instances and actions
+  fused         the T-steps-per-launch rollout kernel on the same workload
+
+For N > 1 the driver launches this under torch.distributed.run, one rank per GPU;
+envs are sharded by global env id, there is no data-path collective (the path
+shards: SURVEY.md 8e), the timed region is bracketed by barriers and the max over
+ranks is reported ("weak" scaling: per-GPU work is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# reference Python step() measured in the build container (tests/golden/GENERATION_REPORT.txt):
+# 1 core, synthetic 10x5 instances, reference env under oracle/ref_shim
+REFERENCE_PYTHON_STEPS_PER_S = 1700.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                         % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the environment kernels")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+
+    N = args.envs_per_gpu
+    first_env = rank * N
+    t0 = time.time()
+    insts = fi.InstanceSet(N).generate_range(1000 + first_env, fi.bench_10x5_params()).solve_fluid()
+    t_prep = time.time() - t0
+    K = np.array([insts.dims(i)["K"] for i in range(N)])
+    Tbuf = 64
+    rs = np.random.RandomState(4242 + rank)
+    actions_h = np.stack([rs.randint(0, 6, (Tbuf, N)), rs.randint(0, 5, (Tbuf, N))], 2).astype(np.uint8)
+    actions = torch.from_numpy(actions_h).cuda(local_rank)
+    env = EnvBatch(insts, N, device=local_rank, rng_seed=20260 + first_env)
+    env.reset()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        env.step(actions[i % Tbuf], autoreset=True)
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        env.step(actions[i % Tbuf], autoreset=True)
+    ev1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
+    status = env.read()["status"]
+    assert int((status != 0).sum().item()) == 0, "an environment reported an error status during the bench"
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline leg: per-launch HIP events on the launch stream ------------------
+    n_ev = min(args.steps, 400)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        env.step(actions[i % Tbuf], autoreset=True)
+        b.record()
+    torch.cuda.synchronize()
+    per_launch_us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    kern_us = float(np.mean(per_launch_us[n_ev // 10: n_ev - n_ev // 10]))     # trimmed mean
+    bytes_per_launch = env.step_bytes * N
+
+    # ---- fused rollout kernel on the same workload ----------------------------------
+    T = int(K.max())
+    fused = None
+    if rank == 0:
+        env2 = EnvBatch(insts, N, device=local_rank, rng_seed=1)
+        reps = 20
+        env2.reset(); env2.rollout(actions[:T], trace=False, rewards=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps):
+            env2.reset()
+            e0.record(); env2.rollout(actions[:T], trace=False, rewards=False); e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        steps_per_rollout = int(K.sum())
+        fused = {"kernel": "rollout_kernel", "env_steps_per_launch": steps_per_rollout,
+                 "ms_per_launch": tot / reps, "env_steps_per_s": steps_per_rollout / (tot / reps * 1e-3),
+                 "achieved_GBps": env.step_bytes * steps_per_rollout / (tot / reps * 1e-3) / 1e9}
+
+    # ---- cpu baseline: the oracle on one host core, bounded sample -------------------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+        n_s = 256
+        envs = []
+        for i in range(n_s):
+            a = insts.arrays(i)
+            envs.append((pyoracle.OracleEnv(a, a.x, rng_seed=env.env_seed(i)), np.ascontiguousarray(actions_h[:, i])))
+        steps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            for oe, act in envs:
+                n, _ = oe.play(act)
+                steps += n
+        dt = time.perf_counter() - t0
+        cpu = {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+               "sample": "oracle/fjsp_oracle.c (scalar C port of the reference, bit-exact to it) replaying full "
+                         "random-policy episodes of the first %d instances of this workload for %.1f s on one host "
+                         "core (%d steps); reference Python itself: ~%.0f env-steps/s on one core (build container, "
+                         "tests/golden/GENERATION_REPORT.txt)" % (n_s, dt, steps, REFERENCE_PYTHON_STEPS_PER_S)}
+
+    if rank == 0:
+        total_steps = N * world * args.steps
+        achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
+        out = {
+            "metric": "env-steps/sec (batched SO_FJSSP 10x5)",
+            "value": total_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d parallel SO_FJSSP 10x5 generated instances per GPU "
+                                   "(seeds 1000+i), random policy, per-step HIP kernel (step_kernel<1>) with autoreset, "
+                                   "one launch = one env step of every env" % N,
+                       "envs_per_gpu": N, "mean_ops_per_instance": float(K.mean()), "sharding": "env id range per rank, no collective",
+                       "host_prep_s": round(t_prep, 3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "step_kernel<1>", "bytes_per_env_step": env.step_bytes,
+                         "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": kern_us,
+                         "region_us_per_launch": region_ms * 1e3 / args.steps},
+            "cpu_baseline": cpu,
+            "fused": fused,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,841 @@
+// gfx950 (MI355X / CDNA4) kernels of the batched rule-dispatch FJSP environment.
+//
+// Execution model: ONE 64-lane WAVEFRONT PER ENVIRONMENT, 4 environments per
+// 256-thread workgroup, no inter-wave communication at all.
+//   * lane l of chunk c owns operation type k = 64c + l (the reference's
+//     kind_task_tuple order): eligibility masks, fluid rates, per-k list
+//     statistics live in that lane's registers;
+//   * lanes 0..M-1 double as machine lanes (time_end, job on the machine);
+//   * the job table (state word, due date, kind info) of the environment is
+//     staged in a wave-private LDS slice; the fused rollout kernel also keeps
+//     the machine x op "unprocessed" matrix there;
+//   * next-event selection is a DPP min-reduction over the machine lanes,
+//     availability sets are 64-bit ballots, rule argmax/argmin walk the ballot
+//     in index order with readlane so the reference's "first extremum wins"
+//     tie-break (CPython max/min) is kept, and every float sum that feeds a
+//     decision or the observation is accumulated serially in the reference's
+//     order (tree reductions would break bit-exactness).  Integer statistics
+//     use DPP row reductions.
+//
+// Reference restated (paths relative to the reference root):
+//   environments/SO_FJSSP.py:51-76    reset            -> init_episode + observe
+//   environments/SO_FJSSP.py:99-166   update_parameter -> compute_params (job-centric form)
+//   environments/SO_FJSSP.py:168-265  step             -> decide / dispatch / advance_clock / observe
+//   environments/SO_FJSSP.py:267-322  task_select, machine_select
+//   environments/SO_FJSSP.py:78-97    state_extract    -> observe
+//   environments/class_FJSSP.py:282-306 update_fluid_parameter -> fluid_tables_kernel
+// Compiled with -ffp-contract=off: a*b+c must round twice like CPython.
+#include <hip/hip_runtime.h>
+
+#include "../../include/fjsp_amd.h"
+#include "fjsp_device.h"
+#include "fjsp_pyset.h"
+
+#pragma clang fp contract(off)
+
+namespace fjsp {
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t rlu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ double rld(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void wave_sync() {
+    // LDS / global traffic of one wave is issued in order; this only stops the
+    // compiler from moving memory operations across the hand-off point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#define DPP(v, ctrl, ident) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), 0xF, 0xF, false)
+// sum over the 64 lanes; every lane must be active.  4 DPP steps give each
+// 16-lane row its total (quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
+// row_mirror), the 4 row totals are combined on the scalar unit.
+__device__ __forceinline__ int wave_sum(int v) {
+    v += DPP(v, 0xB1, 0);
+    v += DPP(v, 0x4E, 0);
+    v += DPP(v, 0x141, 0);
+    v += DPP(v, 0x140, 0);
+    return rl(v, 0) + rl(v, 16) + rl(v, 32) + rl(v, 48);
+}
+__device__ __forceinline__ int wave_min(int v) {
+    v = min(v, DPP(v, 0xB1, 0x7fffffff));
+    v = min(v, DPP(v, 0x4E, 0x7fffffff));
+    v = min(v, DPP(v, 0x141, 0x7fffffff));
+    v = min(v, DPP(v, 0x140, 0x7fffffff));
+    return min(min(rl(v, 0), rl(v, 16)), min(rl(v, 32), rl(v, 48)));
+}
+// exact sum of non-negative 64-bit lane values below 2^47
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    int lo = (int)(v & 0xFFFFFF), hi = (int)(v >> 24);
+    return (long long)wave_sum(lo) + ((long long)wave_sum(hi) << 24);
+}
+template <int KC, class T>
+__device__ __forceinline__ T pick(const T (&a)[KC], int c) {
+    T r = a[0];
+#pragma unroll
+    for (int i = 1; i < KC; ++i)
+        if (c == i) r = a[i];
+    return r;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// ------------------------------------------------------------------ wave state
+template <int KC>
+struct W {
+    const DevBatch *b;
+    int env, inst, lane;
+    // uniform instance dims
+    int K, M, njobs;
+    uint32_t mmask;
+    // uniform dynamic scalars (EnvScalars)
+    int t, step_count, done, n_unassigned, completion, completion_last;
+    uint32_t status, seq_ctr, rng_calls, busy;
+    long long tard_done, delay_sum;
+    uint64_t env_seed;
+    // lane = operation type
+    uint32_t kA[KC], kB[KC], elig[KC], fmask[KC];
+    double rate_sum[KC], time_sum[KC];
+    int nun[KC], cnt_a[KC], cnt_e[KC], max_a[KC], fifo_cnt[KC], head_job[KC], due_min[KC], tard[KC];
+    double max_e[KC], urg[KC];
+    // lane = machine
+    int tend_m, mjob_m;
+    // lane i < 10: previous observation
+    double obs_prev_l;
+    // wave-private LDS
+    uint32_t *jstL;
+    int32_t *dueL;
+    uint32_t *jinfoL;
+    double *scrL;   // 16 doubles of scratch
+    double *unp;    // unprocessed_rj matrix [MP][KP]: LDS slice (rollout) or the HBM rows (step)
+    // static rows of this instance
+    const uint16_t *p_i;
+    const double *rate_i, *arr_i;
+};
+
+__host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, bool un_lds) {
+    return (size_t)JP * 12 + 16 * 8 + (un_lds ? (size_t)MP * KP * 8 : 0);
+}
+
+template <int KC>
+__device__ __forceinline__ void bind(W<KC> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds) {
+    w.b = b;
+    w.env = env;
+    w.lane = (int)__lane_id();
+    w.inst = env % b->n_inst;
+    const InstHeader h = b->ihdr[w.inst];
+    w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
+    w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
+    const int JP = b->JP, KP = b->KP, MP = b->MP;
+    // LDS carve: [scratch 16 f64][un (optional)][jst][due][jinfo]
+    w.scrL = reinterpret_cast<double *>(lds);
+    unsigned char *q = lds + 16 * 8;
+    if (un_lds) { w.unp = reinterpret_cast<double *>(q); q += (size_t)MP * KP * 8; }
+    else w.unp = b->un + (size_t)env * MP * KP;
+    w.jstL = reinterpret_cast<uint32_t *>(q); q += (size_t)JP * 4;
+    w.dueL = reinterpret_cast<int32_t *>(q); q += (size_t)JP * 4;
+    w.jinfoL = reinterpret_cast<uint32_t *>(q);
+    const size_t ko = (size_t)w.inst * KP;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int k = c * kWave + w.lane;
+        w.kA[c] = b->kinfoA[ko + k]; w.kB[c] = b->kinfoB[ko + k];
+        w.elig[c] = b->elig[ko + k]; w.fmask[c] = b->fmask[ko + k];
+        w.rate_sum[c] = b->rate_sum[ko + k]; w.time_sum[c] = b->time_sum[ko + k];
+    }
+    w.p_i = b->p + (size_t)w.inst * MP * KP;
+    w.rate_i = b->rate + (size_t)w.inst * MP * KP;
+    w.arr_i = b->arr + (size_t)w.inst * MP * KP;
+    for (int n = w.lane; n < w.njobs; n += kWave) {
+        w.dueL[n] = b->due[(size_t)w.inst * JP + n];
+        w.jinfoL[n] = b->jinfo[(size_t)w.inst * JP + n];
+    }
+    w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
+}
+
+template <int KC>
+__device__ __forceinline__ void load_dynamic(W<KC> &w, bool un_lds) {
+    const DevBatch *b = w.b;
+    const int MP = b->MP, KP = b->KP, JP = b->JP;
+    const unsigned long long *sw = reinterpret_cast<const unsigned long long *>(b->scal + w.env);
+    unsigned long long word = w.lane < 18 ? sw[w.lane] : 0ull;
+    const int lo = (int)(word & 0xFFFFFFFFull), hi = (int)(word >> 32);
+    w.t = rl(lo, 0); w.step_count = rl(hi, 0);
+    w.done = rl(lo, 1); w.n_unassigned = rl(hi, 1);
+    w.status = (uint32_t)rl(lo, 2); w.seq_ctr = (uint32_t)rl(hi, 2);
+    w.rng_calls = (uint32_t)rl(lo, 3); w.busy = (uint32_t)rl(hi, 3);
+    w.completion = rl(lo, 4); w.completion_last = rl(hi, 4);
+    w.tard_done = (long long)(((unsigned long long)(uint32_t)rl(hi, 5) << 32) | (uint32_t)rl(lo, 5));
+    w.delay_sum = (long long)(((unsigned long long)(uint32_t)rl(hi, 6) << 32) | (uint32_t)rl(lo, 6));
+    // obs_prev[i] sits in word 8+i; move it to lane i
+    {
+        const int src = (w.lane + 8) & 63;
+        const int plo = __builtin_amdgcn_ds_bpermute(src << 2, lo), phi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+        w.obs_prev_l = __hiloint2double(phi, plo);
+    }
+    w.tend_m = w.lane < w.M ? b->tend[(size_t)w.env * MP + w.lane] : 0;
+    w.mjob_m = w.lane < w.M ? b->mjob[(size_t)w.env * MP + w.lane] : -1;
+    for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = b->jst[(size_t)w.env * JP + n];
+    if (un_lds) {
+        const double *src = b->un + (size_t)w.env * MP * KP;
+        for (int m = 0; m < w.M; ++m)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = src[m * KP + c * kWave + w.lane];
+    }
+    wave_sync();
+}
+
+template <int KC>
+__device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
+    const DevBatch *b = w.b;
+    const int MP = b->MP, KP = b->KP, JP = b->JP;
+    wave_sync();
+    // rebuild the 18 words lane-wise
+    unsigned long long word = 0;
+    auto pk = [](uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; };
+    switch (w.lane) {
+    case 0: word = pk((uint32_t)w.t, (uint32_t)w.step_count); break;
+    case 1: word = pk((uint32_t)w.done, (uint32_t)w.n_unassigned); break;
+    case 2: word = pk(w.status, w.seq_ctr); break;
+    case 3: word = pk(w.rng_calls, w.busy); break;
+    case 4: word = pk((uint32_t)w.completion, (uint32_t)w.completion_last); break;
+    case 5: word = (unsigned long long)w.tard_done; break;
+    case 6: word = (unsigned long long)w.delay_sum; break;
+    default: break;
+    }
+    {   // lane i < 10 holds obs_prev[i]; it belongs in word 8+i
+        const int src = (w.lane - 8) & 63;
+        const int lo = __double2loint(w.obs_prev_l), hi = __double2hiint(w.obs_prev_l);
+        const int plo = __builtin_amdgcn_ds_bpermute(src << 2, lo), phi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+        if (w.lane >= 8 && w.lane < 18) word = pk((uint32_t)plo, (uint32_t)phi);
+    }
+    unsigned long long *sw = reinterpret_cast<unsigned long long *>(b->scal + w.env);
+    if (w.lane < 18) sw[w.lane] = word;
+    if (w.lane < w.M) {
+        b->tend[(size_t)w.env * MP + w.lane] = w.tend_m;
+        b->mjob[(size_t)w.env * MP + w.lane] = w.mjob_m;
+    }
+    for (int n = w.lane; n < w.njobs; n += kWave) b->jst[(size_t)w.env * JP + n] = w.jstL[n];
+    if (un_lds) {
+        double *dst = b->un + (size_t)w.env * MP * KP;
+        for (int m = 0; m < w.M; ++m)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) dst[m * KP + c * kWave + w.lane] = w.unp[m * KP + c * kWave + w.lane];
+    }
+}
+
+// ------------------------------------------------ update_parameter, job-centric
+// SO_FJSSP.py:126-154 per operation type k=(r,j): the reference walks
+// task_unprocessed_list[k] (jobs of kind r whose stage-j task is unassigned, in
+// job-number order) with a positional index; here lane k walks the jobs of its
+// kind and keeps the same index.  job_now_list[k] is recovered from the job
+// words: jobs at stage j carrying a FIFO sequence; its head is the smallest
+// sequence (append order, SO_FJSSP.py:215, class_FJSSP.py:225).
+template <int KC>
+__device__ __forceinline__ void compute_params(W<KC> &w) {
+    const int t = w.t;
+    const double td = (double)t;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const uint32_t a = w.kA[c];
+        const int jbeg = (int)(a & 0xFFFFu), jcnt = (int)(a >> 16), j = (int)(w.kB[c] & 0xFFu);
+        const double ts = w.time_sum[c];
+        int idx = 0, cnt_a = 0, cnt_e = 0, max_a = 0, fifo = 0, head = -1, dmin = 0x7fffffff, tard = 0;
+        uint32_t hseq = 0xFFFFFFFFu;
+        double max_e = 0.0, sum_e = 0.0;
+        for (int n = jbeg; n < jbeg + jcnt; ++n) {
+            const uint32_t js = w.jstL[n];
+            const int nj = (int)(js & 0xFFu);
+            if (nj <= j) {
+                const int d = w.dueL[n];
+                const int da = t - d;                                   // :138
+                const double est = td + ts * (double)(idx + 1);        // :136,139
+                const double de = est - (double)d;
+                if (t > d) { cnt_a++; tard += da; }                     // :134-135 (:120-122 for the last stage)
+                if (est > (double)d) cnt_e++;                           // :136-137
+                if (idx == 0) { max_a = da; max_e = de; }
+                else { max_a = max(max_a, da); if (de > max_e) max_e = de; }
+                sum_e = sum_e + de;                                     // :153 sum() left to right
+                idx++;
+                const uint32_t sq = js >> 8;
+                if (nj == j && sq != kNoSeq) {
+                    fifo++;
+                    if (sq < hseq) { hseq = sq; head = n; }
+                    dmin = min(dmin, d);                                // class_FJSSP.py:79-84 due_date_min
+                }
+            }
+        }
+        w.nun[c] = idx; w.cnt_a[c] = cnt_a; w.cnt_e[c] = cnt_e; w.max_a[c] = max_a; w.max_e[c] = max_e;
+        w.fifo_cnt[c] = fifo; w.head_job[c] = head; w.due_min[c] = dmin; w.tard[c] = tard;
+        w.urg[c] = sum_e / (double)idx;                                 // :153 (read only for available k, idx >= 1)
+    }
+}
+
+// first-extremum argmax / argmin over the set bits of a ballot, in index order
+template <int KC>
+__device__ __forceinline__ int argmax_f64(const uint64_t (&mask)[KC], const double (&key)[KC]) {
+    int best = -1;
+    double bv = 0.0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        uint64_t m = mask[c];
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const double v = rld(key[c], l);
+            if (best < 0 || v > bv) { bv = v; best = c * kWave + l; }
+        }
+    }
+    return best;
+}
+template <int KC, bool MAXIMISE>
+__device__ __forceinline__ int argext_i32(const uint64_t (&mask)[KC], const int (&key)[KC]) {
+    int best = -1, bv = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        uint64_t m = mask[c];
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int v = rl(key[c], l);
+            if (best < 0 || (MAXIMISE ? v > bv : v < bv)) { bv = v; best = c * kWave + l; }
+        }
+    }
+    return best;
+}
+template <int KC>
+__device__ __forceinline__ int popc_masks(const uint64_t (&mask)[KC]) {
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) n += __builtin_popcountll(mask[c]);
+    return n;
+}
+template <int KC>
+__device__ __forceinline__ int nth_bit(const uint64_t (&mask)[KC], int idx) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        uint64_t m = mask[c];
+        const int n = __builtin_popcountll(m);
+        if (idx < n) {
+            for (int i = 0; i < idx; ++i) m &= m - 1;
+            return c * kWave + __builtin_ctzll(m);
+        }
+        idx -= n;
+    }
+    return -1;
+}
+// random.choice replacement (fjsp_oracle.h): index into a list of length n
+template <int KC>
+__device__ __forceinline__ int rng_choice(W<KC> &w, int n) {
+    const uint64_t u = splitmix64(w.env_seed + (uint64_t)w.rng_calls);
+    w.rng_calls++;
+    return (int)(((u >> 32) * (uint64_t)n) >> 32);
+}
+
+template <int KC>
+__device__ __forceinline__ bool any_available(const W<KC> &w, uint32_t idle) {
+    uint64_t any = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) any |= __ballot(w.fifo_cnt[c] > 0 && (w.elig[c] & idle) != 0);
+    return any != 0;
+}
+
+// fluid_unprocessed_number (SO_FJSSP.py:239-240) is a pure function of the clock
+// (order_arrive_time = 0 for a single order): Q0 - rate_sum * t.
+template <int KC>
+__device__ __forceinline__ double fluid_q(const W<KC> &w, int c) {
+    const double q0 = (double)(w.kA[c] >> 16);
+    return q0 - w.rate_sum[c] * (double)w.t;
+}
+
+// SO_FJSSP.py:267-298 task_select.  Returns k or -1 (status set).
+template <int KC>
+__device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
+    uint64_t av[KC], fav[KC];
+    uint64_t anyav = 0, anyfav = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const bool has = w.fifo_cnt[c] > 0;
+        av[c] = __ballot(has && (w.elig[c] & idle) != 0);
+        fav[c] = __ballot(has && (w.fmask[c] & idle) != 0);
+        anyav |= av[c]; anyfav |= fav[c];
+    }
+    if (!anyav) { w.status |= FJSP_ST_NO_EVENT; return -1; }
+    switch (a0) {
+    case 0: {   // rule 1 :269-273
+        uint64_t de[KC]; uint64_t any = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) { de[c] = av[c] & __ballot(w.cnt_e[c] > 0); any |= de[c]; }
+        return any ? argmax_f64<KC>(de, w.max_e) : argmax_f64<KC>(av, w.urg);
+    }
+    case 1: {   // rule 2 :274-278
+        uint64_t da[KC]; uint64_t any = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) { da[c] = av[c] & __ballot(w.cnt_a[c] > 0); any |= da[c]; }
+        return any ? argext_i32<KC, true>(da, w.max_a) : argmax_f64<KC>(av, w.urg);
+    }
+    case 2: {   // rule 3 :279-283, Tasks.gap class_FJSSP.py:70-72
+        double gap[KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) gap[c] = (double)w.nun[c] - fluid_q(w, c);
+        return anyfav ? argmax_f64<KC>(fav, gap) : argmax_f64<KC>(av, gap);
+    }
+    case 3:     // rule 4 :284-288
+        return anyfav ? argmax_f64<KC>(fav, w.urg) : argmax_f64<KC>(av, w.urg);
+    case 4:     // rule 5 :289-293
+        return anyfav ? argext_i32<KC, false>(fav, w.due_min) : argext_i32<KC, false>(av, w.due_min);
+    case 5:     // rule 6 :294-295
+        return nth_bit<KC>(av, rng_choice(w, popc_masks<KC>(av)));
+    default:
+        w.status |= FJSP_ST_BAD_TASK_RULE;      // MyError :297
+        return -1;
+    }
+}
+
+// Machine.gap_ave (class_FJSSP.py:144-146) for one machine: serial sum over
+// kind_task_tuple order of unprocessed - fluid_unprocessed, divided by (n + 1e-18).
+template <int KC>
+__device__ __forceinline__ double machine_gap_ave(const W<KC> &w, int m) {
+    const int KP = w.b->KP;
+    const double dt = (double)w.t;
+    double s = 0.0;
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int k = c * kWave + w.lane;
+        const int pm = w.p_i[m * KP + k];
+        double g = 0.0;
+        if (pm > 0) g = w.unp[m * KP + k] - (w.arr_i[m * KP + k] - dt * w.rate_i[m * KP + k]);
+        uint64_t em = __ballot(pm > 0);
+        n += __builtin_popcountll(em);
+        while (em) {
+            const int l = __builtin_ctzll(em);
+            em &= em - 1;
+            s = s + rld(g, l);
+        }
+    }
+    return s / ((double)n + 1e-18);
+}
+
+// SO_FJSSP.py:300-322 machine_select.  Candidate lists are visited in CPython's
+// list(set & set) order (fjsp_pyset.h): ascending for M <= 8, not always beyond.
+template <int KC>
+__device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint32_t idle) {
+    const int KP = w.b->KP;
+    const int cs = k_sel >> 6, ls = k_sel & 63;
+    const uint32_t elig_s = rlu(pick<KC>(w.elig, cs), ls), fm_s = rlu(pick<KC>(w.fmask, cs), ls);
+    const uint32_t first4 = uniu(w.b->efirst4[(size_t)w.inst * KP + k_sel]);
+    const CandList sel = pyset_and(idle, elig_s, first4, false);   // machine_selectable_list :302
+    const CandList fsel = pyset_and(idle, fm_s, 0u, true);         // fluid_machine_selectable_list :303
+    if (sel.n == 0) { w.status |= FJSP_ST_NO_EVENT; return -1; }
+    // lane m: gap_rj_dict[m][k_sel] (class_FJSSP.py:137-142) and p[m][k_sel]
+    double g = 0.0;
+    int pm = 0;
+    if (w.lane < w.M && ((sel.mask >> w.lane) & 1u)) {
+        const int o = w.lane * KP + k_sel;
+        pm = w.p_i[o];
+        g = w.unp[o] - (w.arr_i[o] - (double)w.t * w.rate_i[o]);
+    }
+    auto visit = [&](const CandList &l, auto &&f) {
+        if (l.asc) { uint32_t m = l.mask; while (m) { f((int)__builtin_ctz(m)); m &= m - 1; } }
+        else for (int i = 0; i < l.n; ++i) f((int)((l.packed >> (8 * i)) & 0xFFu));
+    };
+    auto argmax_gap = [&](const CandList &l) {
+        int best = -1; double bv = 0.0;
+        visit(l, [&](int m) { const double v = rld(g, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        return best;
+    };
+    auto argmin_p = [&](const CandList &l) {
+        int best = -1, bv = 0;
+        visit(l, [&](int m) { const int v = rl(pm, m); if (best < 0 || v < bv) { bv = v; best = m; } });
+        return best;
+    };
+    auto argmax_gave = [&](const CandList &l) {
+        if (l.n == 1) return (int)__builtin_ctz(l.mask);
+        int best = -1; double bv = 0.0;
+        visit(l, [&](int m) { const double v = machine_gap_ave<KC>(w, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        return best;
+    };
+    switch (a1) {
+    case 0: return argmax_gap(fsel.n ? fsel : sel);       // rule 1 :304-308
+    case 1: return argmax_gap(sel);                       // rule 2 :309-310
+    case 2: return argmin_p(sel);                         // rule 3 :311-312
+    case 3: return argmax_gave(fsel.n ? fsel : sel);      // rule 4 :313-317
+    case 4: return cand_at(sel, rng_choice(w, sel.n));    // rule 5 :318-319
+    default:
+        w.status |= FJSP_ST_BAD_MACHINE_RULE;             // MyError :321
+        return -1;
+    }
+}
+
+// SO_FJSSP.py:176-250: dispatch the FIFO head of k_sel on m_sel, then advance
+// the clock until some operation type is available again (or the episode ends).
+template <int KC>
+__device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_sel) {
+    const int KP = w.b->KP;
+    const int cs = k_sel >> 6, ls = k_sel & 63;
+    const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
+    const int Jr = (int)((rlu(pick<KC>(w.kB, cs), ls) >> 8) & 0xFFu);
+    const int pm = w.p_i[m_sel * KP + k_sel];
+    const int time_end = w.t + pm;                                           // :184
+    const uint32_t js = w.jstL[job];
+    const int nj = (int)(js & 0xFFu) + 1;
+    if (w.lane == 0) {
+        w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);                        // :186-191
+        w.unp[m_sel * KP + k_sel] -= 1.0;                                    // :198
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+        if (c == cs && w.lane == ls) w.fifo_cnt[c]--;
+    if (w.lane == m_sel) { w.tend_m = time_end; w.mjob_m = job; }           // :194-197
+    w.busy |= 1u << m_sel;
+    if (time_end > w.completion) w.completion = time_end;
+    if (nj == Jr) {                                                          // :200-202
+        w.n_unassigned--;
+        const int late = time_end - w.dueL[job];
+        w.tard_done += late > 0 ? late : 0;
+    }
+    uint32_t idle = ~w.busy & w.mmask;
+    while (!any_available<KC>(w, idle)) {                                    // :204
+        const int cand = (w.lane < w.M && w.tend_m > w.t) ? w.tend_m : 0x7fffffff;
+        const int tn = wave_min(cand);                                       // :205-207 next event
+        if (tn == 0x7fffffff) { w.status |= FJSP_ST_NO_EVENT; break; }
+        w.t = tn;
+        uint64_t fin = __ballot(w.lane < w.M && w.tend_m == tn);            // :209-215, ascending m
+        while (fin) {
+            const int m = __builtin_ctzll(fin);
+            fin &= fin - 1;
+            const int jb = rl(w.mjob_m, m);
+            const uint32_t s2 = w.jstL[jb];
+            const uint32_t ji = w.jinfoL[jb];
+            const int n2 = (int)(s2 & 0xFFu), J2 = (int)((ji >> 16) & 0xFFu);
+            if (n2 < J2) {
+                const int kk = (int)(ji & 0xFFFFu) + n2;
+                if (w.lane == 0) w.jstL[jb] = jst_pack(w.seq_ctr, (uint32_t)n2);
+                w.seq_ctr++;
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+                    if (c == (kk >> 6) && w.lane == (kk & 63)) w.fifo_cnt[c]++;
+            }
+        }
+        w.busy &= ~(uint32_t)__ballot(w.lane < w.M && w.tend_m <= tn);      // :233-235
+        idle = ~w.busy & w.mmask;
+        if (w.n_unassigned == 0) { w.done = 1; break; }                      // :247-250
+    }
+    wave_sync();
+}
+
+// SO_FJSSP.py:78-97 state_extract (+ the ratios of update_parameter :156-165).
+// Needs compute_params() at the current clock.  Returns tard_unproc
+// (delay_time_sum_unprocessed, :110-122) and leaves obs[0..n_obs) in LDS scratch.
+template <int KC>
+__device__ __forceinline__ long long observe(W<KC> &w) {
+    const int K = w.K, M = w.M;
+    // ---- integer statistics (order-free): DPP reductions
+    int nun_s = 0, a_s = 0, e_s = 0, ja_s = 0, je_s = 0, jn_s = 0;
+    long long tu = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const bool last = ((w.kB[c] >> 24) & 1u) != 0;
+        nun_s += w.nun[c]; a_s += w.cnt_a[c]; e_s += w.cnt_e[c];
+        if (last) { ja_s += w.cnt_a[c]; je_s += w.cnt_e[c]; jn_s += w.nun[c]; tu += w.tard[c]; }
+    }
+    const int task_number = wave_sum(nun_s), delay_a = wave_sum(a_s), delay_e = wave_sum(e_s);
+    const int job_a = wave_sum(ja_s), job_e = wave_sum(je_s), job_number = wave_sum(jn_s);
+    const long long tard_unproc = wave_sum_i64(tu);
+    // ---- machine completion-time spread (:84-87)
+    const int tsum = wave_sum(w.lane < M ? w.tend_m : 0);
+    const double ct_ave = (double)tsum / (double)M;
+    double s = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const double d = (double)rl(w.tend_m, m) - ct_ave;
+        s = s + d * d;                                   // math.pow(d, 2)
+    }
+    const double ct_std = sqrt(s / (double)M);
+    // ---- per operation type rates (class_FJSSP.py:66-76), serial sums in r-major order (:88-95)
+    double fr[KC], gr[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int tot = (int)(w.kA[c] >> 16);
+        fr[c] = (double)(tot - w.nun[c]) / (double)tot;                      // finish_rate
+        gr[c] = ((double)w.nun[c] - fluid_q(w, c)) / (double)tot;            // gap_rate
+    }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int cnt = min(kWave, K - c * kWave);
+        for (int i = 0; i < cnt; ++i) { s1 = s1 + rld(fr[c], i); s2 = s2 + rld(gr[c], i); }
+    }
+    const double cro_ave = s1 / (double)K, gap_ave = s2 / (double)K;
+    double v1 = 0.0, v2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int cnt = min(kWave, K - c * kWave);
+        for (int i = 0; i < cnt; ++i) {
+            const double d1 = rld(fr[c], i) - cro_ave, d2 = rld(gr[c], i) - gap_ave;
+            v1 = v1 + d1 * d1; v2 = v2 + d2 * d2;
+        }
+    }
+    const double cro_std = sqrt(v1 / (double)K), gap_std = sqrt(v2 / (double)K);
+    double dro_a = 0.0, dro_e = 0.0, drj_a = 0.0, drj_e = 0.0;
+    if (!w.done) {                                                           // :156-165
+        dro_a = (double)delay_a / (double)task_number; dro_e = (double)delay_e / (double)task_number;
+        drj_a = (double)job_a / (double)job_number; drj_e = (double)job_e / (double)job_number;
+    }
+    if (w.lane == 0) {
+        int i = 0;
+        if (w.b->variant == FJSP_VARIANT_SO_FJSSP) w.scrL[i++] = (double)M;
+        w.scrL[i++] = ct_std; w.scrL[i++] = cro_ave; w.scrL[i++] = cro_std; w.scrL[i++] = gap_ave;
+        w.scrL[i++] = gap_std; w.scrL[i++] = dro_a; w.scrL[i++] = dro_e; w.scrL[i++] = drj_a; w.scrL[i++] = drj_e;
+    }
+    wave_sync();
+    return tard_unproc;
+}
+
+// state = [static, v(t), v(t) - v(t-1)]  (SO_FJSSP.py:71-72,257-258); updates obs_prev.
+template <int KC>
+__device__ __forceinline__ void emit_state(W<KC> &w, double *state_out, bool zero_gap) {
+    const int n_obs = w.b->n_obs, n_static = w.b->n_static;
+    const double cur = w.lane < n_obs ? w.scrL[w.lane] : 0.0;
+    const double gap = zero_gap ? cur - cur : cur - w.obs_prev_l;
+    if (w.lane < n_obs) w.obs_prev_l = cur;
+    if (state_out) {
+        double *o = state_out + (size_t)w.env * w.b->state_size;
+        if (w.lane < n_static) o[w.lane] = w.b->sstate[(size_t)w.inst * 8 + w.lane];
+        if (w.lane < n_obs) { o[n_static + w.lane] = cur; o[n_static + n_obs + w.lane] = gap; }
+    }
+    wave_sync();
+}
+
+// SO_FJSSP.py:51-76 reset (fresh-object semantics; class_FJSSP.py:173-244 for one order).
+template <int KC>
+__device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
+    const int KP = w.b->KP;
+    w.t = 0; w.step_count = 0; w.done = 0; w.n_unassigned = w.njobs; w.status = 0;
+    w.seq_ctr = (uint32_t)w.njobs; w.busy = 0; w.completion = 0; w.completion_last = 0;
+    w.tard_done = 0; w.delay_sum = 0;
+    w.tend_m = 0; w.mjob_m = -1;
+    for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack((uint32_t)n, 0u);  // class_FJSSP.py:225
+    for (int m = 0; m < w.M; ++m)                                                        // :304
+#pragma unroll
+        for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = w.arr_i[m * KP + c * kWave + w.lane];
+    wave_sync();
+    compute_params<KC>(w);
+    observe<KC>(w);                      // delay_time_sum_unprocessed is 0-relevant only after a step
+    emit_state<KC>(w, state_out, true);
+}
+
+// One environment step.  compute_params() must be current on entry and is
+// current again on exit (the fused kernel carries it across steps).
+template <int KC>
+__device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, double *state_out, int *k_out, int *m_out) {
+    const uint32_t idle = ~w.busy & w.mmask;
+    const int k_sel = task_select<KC>(w, a0, idle);
+    const int m_sel = k_sel >= 0 ? machine_select<KC>(w, a1, k_sel, idle) : -1;
+    *k_out = k_sel; *m_out = m_sel;
+    if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
+    dispatch_and_advance<KC>(w, k_sel, m_sel);
+    w.step_count++;                                                          // :252
+    compute_params<KC>(w);
+    const long long tard_unproc = observe<KC>(w);                           // :256
+    emit_state<KC>(w, state_out, false);
+    const long long delay_new = w.tard_done + tard_unproc;                   // :259
+    const long long delta = delay_new - w.delay_sum;
+    w.delay_sum = delay_new;                                                 // :263
+    w.completion_last = w.completion;
+    return (double)(-delta);                                                 // :328 (exact integer)
+}
+
+// ------------------------------------------------------------------------ kernels
+// update_fluid_parameter (class_FJSSP.py:282-306): one thread per (instance, k).
+__global__ void fluid_tables_kernel(DevBatch b) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= b.n_inst * b.KP) return;
+    const int inst = idx / b.KP, k = idx % b.KP;
+    const InstHeader h = b.ihdr[inst];
+    const size_t mo = (size_t)inst * b.MP * b.KP;
+    uint32_t fm = 0;
+    double s = 0.0;
+    const double q0 = (double)(b.kinfoA[(size_t)inst * b.KP + k] >> 16);
+    for (int m = 0; m < h.M; ++m) {
+        const int pm = b.p[mo + (size_t)m * b.KP + k];
+        double r = 0.0;
+        if (k < h.K && pm > 0) {
+            const double xv = b.x[mo + (size_t)m * b.KP + k];
+            r = xv * (1.0 / (double)pm);                // :164, :288-289
+            if (xv != 0) fm |= 1u << m;                 // :290-292
+            s = s + r;                                  // :294 (ascending m)
+        }
+        b.rate[mo + (size_t)m * b.KP + k] = r;
+    }
+    const bool valid = k < h.K;
+    b.fmask[(size_t)inst * b.KP + k] = fm;
+    b.rate_sum[(size_t)inst * b.KP + k] = valid ? s : 0.0;
+    b.time_sum[(size_t)inst * b.KP + k] = valid ? 1.0 / s : 0.0;            // :295
+    for (int m = 0; m < h.M; ++m) {
+        const int pm = b.p[mo + (size_t)m * b.KP + k];
+        double a = 0.0;
+        if (valid && pm > 0) a = (q0 * b.rate[mo + (size_t)m * b.KP + k]) / s;   // :300-302
+        b.arr[mo + (size_t)m * b.KP + k] = a;
+    }
+}
+
+extern __shared__ unsigned char fjsp_lds[];
+
+template <int KC>
+__global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *mask, double *state_out) {
+    const int wave = threadIdx.x >> 6;
+    const int env = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (env >= b.N) return;
+    if (mask && mask[env] == 0) return;
+    W<KC> w;
+    bind<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false);
+    // rng_calls survives a reset (the reference's global `random` state does too)
+    const unsigned long long *sw = reinterpret_cast<const unsigned long long *>(b.scal + env);
+    w.rng_calls = (uint32_t)(sw[3] & 0xFFFFFFFFull);
+    w.obs_prev_l = 0.0;
+    init_episode<KC>(w, state_out);
+    store_dynamic<KC>(w, false);
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void step_kernel(DevBatch b, const uint8_t *actions, int autoreset, double *state_out,
+                                                   double *reward_out, uint8_t *done_out, int16_t *trace_km) {
+    const int wave = threadIdx.x >> 6;
+    const int env = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (env >= b.N) return;
+    W<KC> w;
+    bind<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false);
+    load_dynamic<KC>(w, false);
+    if (w.done) {
+        if (!autoreset) {
+            w.status |= FJSP_ST_STEP_AFTER_DONE;
+            if (w.lane == 0) {
+                reinterpret_cast<uint32_t *>(b.scal + env)[4] = w.status;
+                if (reward_out) reward_out[env] = 0.0;
+                if (done_out) done_out[env] = 1;
+                if (trace_km) { trace_km[(size_t)env * 2] = -1; trace_km[(size_t)env * 2 + 1] = -1; }
+            }
+            return;
+        }
+        init_episode<KC>(w, nullptr);
+    } else {
+        compute_params<KC>(w);
+    }
+    const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
+    int k_sel, m_sel;
+    const double reward = env_step<KC>(w, uni(a0), uni(a1), state_out, &k_sel, &m_sel);
+    if (w.lane == 0) {
+        if (reward_out) reward_out[env] = reward;
+        if (done_out) done_out[env] = (uint8_t)w.done;
+        if (trace_km) { trace_km[(size_t)env * 2] = (int16_t)k_sel; trace_km[(size_t)env * 2 + 1] = (int16_t)m_sel; }
+    }
+    store_dynamic<KC>(w, false);
+}
+
+// T fused steps per launch: the environment lives in registers + LDS for the whole episode.
+template <int KC>
+__global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t *actions, int T, int16_t *trace_km,
+                                                      double *reward_out, double *state_last) {
+    const int wave = threadIdx.x >> 6;
+    const int env = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (env >= b.N) return;
+    W<KC> w;
+    bind<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, true), true);
+    load_dynamic<KC>(w, true);
+    compute_params<KC>(w);
+    for (int s = 0; s < T; ++s) {
+        const size_t o = (size_t)s * b.N + env;
+        int k_sel = -1, m_sel = -1;
+        double reward = 0.0;
+        const bool live = !w.done && !(w.status & (FJSP_ST_BAD_TASK_RULE | FJSP_ST_BAD_MACHINE_RULE | FJSP_ST_NO_EVENT));
+        if (live) {
+            const int a0 = actions[o * 2], a1 = actions[o * 2 + 1];
+            reward = env_step<KC>(w, uni(a0), uni(a1), state_last, &k_sel, &m_sel);
+        }
+        if (w.lane == 0) {
+            if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }
+            if (reward_out) reward_out[o] = reward;
+        }
+    }
+    store_dynamic<KC>(w, true);
+}
+
+// attribute read-back: one thread per environment
+__global__ void read_kernel(DevBatch b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
+                            int32_t *step_count, uint8_t *done, uint32_t *status) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= b.N) return;
+    const EnvScalars s = b.scal[env];
+    const int M = b.ihdr[env % b.n_inst].M;
+    int mx = 0;
+    for (int m = 0; m < M; ++m) mx = max(mx, b.tend[(size_t)env * b.MP + m]);   // SO_FJSSP.py:427 max time_end
+    if (delay) delay[env] = s.delay_sum;
+    if (makespan) makespan[env] = mx;
+    if (completion) completion[env] = s.completion;
+    if (step_time) step_time[env] = s.t;
+    if (step_count) step_count[env] = s.step_count;
+    if (done) done[env] = (uint8_t)s.done;
+    if (status) status[env] = s.status;
+}
+
+// ------------------------------------------------------------------ host launchers
+static inline dim3 grid_for(int N) { return dim3((unsigned)((N + 3) / 4)); }
+
+int launch_fluid_tables(const DevBatch &b, hipStream_t st) {
+    const int n = b.n_inst * b.KP;
+    hipLaunchKernelGGL(fluid_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+#define DISPATCH_KC(kc, CALL)                     \
+    switch (kc) {                                 \
+    case 1: { constexpr int KC = 1; CALL; } break; \
+    case 2: { constexpr int KC = 2; CALL; } break; \
+    case 4: { constexpr int KC = 4; CALL; } break; \
+    default: return -1;                           \
+    }
+
+int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStream_t st) {
+    const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    DISPATCH_KC(b.KC, hipLaunchKernelGGL((reset_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, mask, state));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_step(const DevBatch &b, const uint8_t *actions, int autoreset, double *state, double *reward, uint8_t *done,
+                int16_t *trace_km, hipStream_t st) {
+    const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    DISPATCH_KC(b.KC, hipLaunchKernelGGL((step_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, autoreset,
+                                         state, reward, done, trace_km));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+size_t rollout_lds_bytes(const DevBatch &b) { return 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, true); }
+int launch_rollout(const DevBatch &b, const uint8_t *actions, int T, int16_t *trace_km, double *reward,
+                   double *state_last, hipStream_t st) {
+    const size_t lds = rollout_lds_bytes(b);
+    DISPATCH_KC(b.KC, {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<KC>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((rollout_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, T, trace_km, reward,
+                           state_last);
+    });
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
+                int32_t *step_count, uint8_t *done, uint32_t *status, hipStream_t st) {
+    hipLaunchKernelGGL(read_kernel, dim3((unsigned)((b.N + 255) / 256)), dim3(256), 0, st, b, delay, makespan,
+                       completion, step_time, step_count, done, status);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace fjsp

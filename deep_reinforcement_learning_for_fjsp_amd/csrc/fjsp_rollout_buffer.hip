@@ -1,0 +1,164 @@
+// On-policy rollout buffer in HBM behind the C ABI (include/fjsp_amd.h).
+//
+// Replaces the reference's Replay_Buffer (agents/MPPPO/Buffer.py:7-58: a Python
+// deque of namedtuples that is vstack-ed and copied host->device once per
+// episode) by a [T][N][...] f32 slab the batched step writes into directly and
+// the PyTorch side wraps without copy, plus the discounted-return reverse scan
+// of agents/MPPPO/MPPPO.py:301-312.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/fjsp_amd.h"
+#include "fjsp_host.h"
+
+#pragma clang fp contract(off)
+
+struct fjsp_rollout {
+    int T = 0, N = 0, S = 0, device = 0, len = 0;
+    float *states = nullptr, *actions = nullptr, *rewards = nullptr, *next_states = nullptr, *dones = nullptr,
+          *valid = nullptr, *returns = nullptr;
+};
+
+namespace {
+
+// one thread per (env, state element): Buffer.py:41-45 `.float()` conversions
+__global__ void append_kernel(int N, int S, const double *state, const uint8_t *actions, const double *reward,
+                              const double *next_state, const uint8_t *done, const uint8_t *active, float *o_state,
+                              float *o_actions, float *o_reward, float *o_next, float *o_done, float *o_valid) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * S) return;
+    const size_t env = idx / S, i = idx % S;
+    o_state[idx] = (float)state[idx];
+    o_next[idx] = (float)next_state[idx];
+    if (i == 0) {
+        o_actions[env * 2] = (float)actions[env * 2];
+        o_actions[env * 2 + 1] = (float)actions[env * 2 + 1];
+        o_reward[env] = (float)reward[env];
+        o_done[env] = (float)done[env];
+        o_valid[env] = active ? (float)(active[env] != 0) : 1.0f;
+    }
+}
+
+// MPPPO.py:301-312: G_t = r_t + gamma * G_{t+1}, walking the episode backwards.
+// The reference does this arithmetic on f32 tensor elements (rewards come out of
+// Buffer.sample() as float32; `discount_rate * tensor` and `+` are separate f32
+// ops), so the scan is f32 with two roundings per step.  Rows that are not
+// valid (env finished earlier) are skipped and get a 0 return.
+__global__ void returns_kernel(int T, int N, float gamma, const float *reward, const float *valid, float *returns) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    float g = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * N + env;
+        if (valid[o] != 0.0f) {
+            g = __fadd_rn(reward[o], __fmul_rn(gamma, g));
+            returns[o] = g;
+        } else {
+            returns[o] = 0.0f;
+        }
+    }
+}
+
+bool ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    fjsp::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fjsp_rollout_create(int32_t T, int32_t N, int32_t state_size, int32_t device, fjsp_rollout **out) {
+    if (T <= 0 || N <= 0 || state_size <= 0 || !out) { fjsp::set_error("fjsp_rollout_create: bad arguments"); return FJSP_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        fjsp::set_error("fjsp_rollout_create: no such HIP device"); return FJSP_E_HIP;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(device);
+    auto *b = new fjsp_rollout();
+    b->T = T; b->N = N; b->S = state_size; b->device = device;
+    const size_t tn = (size_t)T * N;
+    bool good = ok(hipMalloc((void **)&b->states, tn * state_size * 4), "hipMalloc states") &&
+                ok(hipMalloc((void **)&b->next_states, tn * state_size * 4), "hipMalloc next_states") &&
+                ok(hipMalloc((void **)&b->actions, tn * 2 * 4), "hipMalloc actions") &&
+                ok(hipMalloc((void **)&b->rewards, tn * 4), "hipMalloc rewards") &&
+                ok(hipMalloc((void **)&b->dones, tn * 4), "hipMalloc dones") &&
+                ok(hipMalloc((void **)&b->valid, tn * 4), "hipMalloc valid") &&
+                ok(hipMalloc((void **)&b->returns, tn * 4), "hipMalloc returns");
+    if (good) good = ok(hipMemset(b->valid, 0, tn * 4), "hipMemset") && ok(hipMemset(b->returns, 0, tn * 4), "hipMemset");
+    (void)hipSetDevice(prev);
+    if (!good) { fjsp_rollout_destroy(b); return FJSP_E_HIP; }
+    *out = b;
+    return FJSP_OK;
+}
+
+void fjsp_rollout_destroy(fjsp_rollout *b) {
+    if (!b) return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(b->device);
+    for (float *p : {b->states, b->actions, b->rewards, b->next_states, b->dones, b->valid, b->returns})
+        if (p) (void)hipFree(p);
+    (void)hipSetDevice(prev);
+    delete b;
+}
+
+int fjsp_rollout_append(fjsp_rollout *b, const double *d_state, const uint8_t *d_actions, const double *d_reward,
+                        const double *d_next_state, const uint8_t *d_done, const uint8_t *d_active, void *stream) {
+    if (!b || !d_state || !d_actions || !d_reward || !d_next_state || !d_done) { fjsp::set_error("fjsp_rollout_append: null argument"); return FJSP_E_ARG; }
+    if (b->len >= b->T) { fjsp::set_error("fjsp_rollout_append: buffer full"); return FJSP_E_STATE; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(b->device);
+    const size_t t = (size_t)b->len, N = (size_t)b->N, S = (size_t)b->S;
+    const size_t n = N * S;
+    hipLaunchKernelGGL(append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->N, b->S,
+                       d_state, d_actions, d_reward, d_next_state, d_done, d_active, b->states + t * n,
+                       b->actions + t * N * 2, b->rewards + t * N, b->next_states + t * n, b->dones + t * N,
+                       b->valid + t * N);
+    const bool good = ok(hipGetLastError(), "append_kernel");
+    (void)hipSetDevice(prev);
+    if (!good) return FJSP_E_HIP;
+    b->len++;
+    return FJSP_OK;
+}
+
+int fjsp_rollout_returns(fjsp_rollout *b, double gamma, void *stream) {
+    if (!b) { fjsp::set_error("fjsp_rollout_returns: null buffer"); return FJSP_E_ARG; }
+    if (b->len == 0) return FJSP_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(b->device);
+    hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((b->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->len,
+                       b->N, (float)gamma, b->rewards, b->valid, b->returns);
+    const bool good = ok(hipGetLastError(), "returns_kernel");
+    (void)hipSetDevice(prev);
+    return good ? FJSP_OK : FJSP_E_HIP;
+}
+
+int fjsp_rollout_clear(fjsp_rollout *b) {
+    if (!b) { fjsp::set_error("fjsp_rollout_clear: null buffer"); return FJSP_E_ARG; }
+    b->len = 0;
+    return FJSP_OK;
+}
+int fjsp_rollout_len(const fjsp_rollout *b) { return b ? b->len : 0; }
+
+void *fjsp_rollout_ptr(fjsp_rollout *b, int32_t which) {
+    if (!b) return nullptr;
+    switch (which) {
+    case 0: return b->states;
+    case 1: return b->actions;
+    case 2: return b->rewards;
+    case 3: return b->next_states;
+    case 4: return b->dones;
+    case 5: return b->valid;
+    case 6: return b->returns;
+    default: return nullptr;
+    }
+}
+
+}  // extern "C"

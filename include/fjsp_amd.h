@@ -162,6 +162,12 @@ int fjsp_env_machine_time_end(fjsp_env *e, int32_t *d_tend, int32_t m_stride, vo
 /* fluid tables of env i copied to host (tests): rate/arr [K*M] k-major, rate_sum/time_sum [K]. */
 int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
                           double *h_rate_sum, double *h_time_sum);
+/* Test hook (host build of csrc/fjsp_pyset.h, the code machine_select runs on the
+ * device): iteration order of list(set(idle) & set(machines)) as CPython 3.10
+ * produces it (SO_FJSSP.py:302-303).  idle_mask bit m = machine m idle;
+ * machines[n] in tuple order (ascending != 0: inserted in ascending order).
+ * Writes the order to out[], returns its length (or a negative error). */
+int fjsp_pyset_and_order(uint32_t idle_mask, const int32_t *machines, int32_t n, int32_t ascending, int32_t *out);
 /* HBM bytes the step kernel reads+writes per env-step (algorithmic). */
 int64_t fjsp_env_step_bytes(const fjsp_env *e);
 

@@ -690,6 +690,22 @@ int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion,
 void fjo_set_ddt(fjo_env *e, double ddt) { e->static_state[0] = ddt; }
 
 
+/* reset + play actions[t][2] until done (or max_T), all in C: the cpu_baseline timing loop */
+int fjo_play(fjo_env *e, const unsigned char *actions, int max_T, double *reward_sum) {
+    double st[64], r, acc = 0.0;
+    int done = 0, t = 0;
+    int rc = fjo_reset(e, st);
+    if (rc) return rc;
+    while (!done && t < max_T) {
+        rc = fjo_step(e, actions[2 * t], actions[2 * t + 1], st, &r, &done, NULL);
+        if (rc) return rc;
+        acc += r;
+        t++;
+    }
+    if (reward_sum) *reward_sum = acc;
+    return t;
+}
+
 int     fjo_step_time(const fjo_env *e) { return e->step_time; }
 int     fjo_step_count(const fjo_env *e) { return e->step_count; }
 int64_t fjo_delay_time_sum(const fjo_env *e) { return e->delay_sum; }

@@ -73,6 +73,10 @@ int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion,
 /* self.DDT as the instance source parsed it (static state element 0 of the MO variant). */
 void fjo_set_ddt(fjo_env *e, double ddt);
 
+/* reset + step through actions[t][2] until done or max_T, entirely in C (cpu_baseline
+ * timing without interpreter overhead).  Returns the number of steps, <0 on error. */
+int fjo_play(fjo_env *e, const unsigned char *actions, int max_T, double *reward_sum);
+
 /* read-back of attributes agents/harnesses read. */
 int     fjo_step_time(const fjo_env *e);
 int     fjo_step_count(const fjo_env *e);

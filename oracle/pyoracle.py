@@ -59,6 +59,7 @@ def lib():
         L.fjo_fluid_completed_time.argtypes = [C.c_void_p]
         L.fjo_fluid_completed_time.restype = C.c_double
         L.fjo_fluid_tables.argtypes = [C.c_void_p] * 5
+        L.fjo_play.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.fjo_pyset_and_list.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
@@ -151,6 +152,15 @@ class OracleEnv(object):
         self.done = bool(done.value)
         self.trace = tr
         return st, rew.value, self.done
+
+    def play(self, actions):
+        """reset + full episode in C (timing loop). Returns (steps, reward_sum)."""
+        actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        acc = C.c_double()
+        n = self.L.fjo_play(self.h, actions.ctypes.data, len(actions), C.byref(acc))
+        if n < 0:
+            raise RuntimeError("oracle play failed rc=%d" % n)
+        return n, acc.value
 
     @property
     def step_time(self):

@@ -313,6 +313,8 @@ def main():
     def suite(name, cases, plans_store, plans_verify, full_state_eps):
         """cases: list of (label, InstanceSet, idx, folder_parent, folder_name)."""
         store = {}
+        suite_base = splitmix64(sum(ord(ch) for ch in name) * 7919)
+        store["rng_seed_base"] = np.uint64(suite_base)
         n_eps = n_steps = 0
         timing = [0.0, 0]
         ep_id = 0
@@ -322,7 +324,11 @@ def main():
             checked_loader = False
             for (kind, seed, keep) in plans_store(ci) + [(k_, s_, False) for (k_, s_) in plans_verify(ci)]:
                 actions = action_stream(kind, seed, Tmax)
-                rng_seed = splitmix64(seed * 1000003 + ci)
+                # stored episode e of a suite plays with random.choice stream seed
+                # suite_base + e * 1000003 == the seed env e of a batch created with
+                # rng_seed = suite_base gets (fjsp_kernels.hip bind()); verify-only
+                # episodes use an unrelated seed
+                rng_seed = (suite_base + ep_id * 1000003) & MASK64 if keep else splitmix64(seed * 1000003 + ci)
                 ref, env = run_reference(SO_FJSSP_Environment, arr, parent, folder, actions, rng_seed,
                                          check_lp=(n_eps % 16 == 0), timing=timing)
                 if not checked_loader:

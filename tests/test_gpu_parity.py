@@ -1,0 +1,215 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden reference
+traces and against the C oracle, on the same instances, fluid solution, actions
+and random.choice stream.
+
+Bars: operation/machine choices, rewards, done flags, clocks, tardiness,
+makespan and machine completion times BIT-EXACT; state vectors bit-exact except
+the three math.pow()-derived entries (tests/helpers.py POW_COLS), which are held
+to 1e-12 (the north star allows 1e-5).
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_gpu(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _batch_for(suite, torch):
+    """One env per stored episode: env e <- (instance of episode e, rng stream of episode e)."""
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+    insts, eps, base = H.load_suite(suite)
+    s = H.instance_set_from([insts[ep["inst"]] for ep in eps])
+    b = EnvBatch(s, len(eps), rng_seed=base)
+    for e, ep in enumerate(eps):
+        assert b.env_seed(e) == ep["rng_seed"]
+    T = max(ep["T"] for ep in eps)
+    actions = np.zeros((T, len(eps), 2), np.uint8)
+    for e, ep in enumerate(eps):
+        actions[:ep["T"], e] = ep["actions"]
+    return insts, eps, b, torch.from_numpy(actions).to(b.device), T
+
+
+@pytest.mark.parametrize("suite", H.SUITES)
+def test_fluid_tables_match_oracle(torch_gpu, suite):
+    """update_fluid_parameter on the device == the oracle's tables (class_FJSSP.py:282-306), bit-exact."""
+    from oracle import pyoracle
+    insts, eps, b, _, _ = _batch_for(suite, torch_gpu)
+    seen = set()
+    for e, ep in enumerate(eps):
+        if ep["inst"] in seen:
+            continue
+        seen.add(ep["inst"])
+        a = insts[ep["inst"]]
+        env = pyoracle.OracleEnv(a, a.x)
+        env.reset()
+        want = env.fluid_tables()
+        got = b.fluid_tables(e)
+        for g, w, name in zip(got, want, ("rate", "arr", "rate_sum", "time_sum")):
+            assert np.array_equal(H.bits(g), H.bits(w)), (suite, a.name, name)
+
+
+@pytest.mark.parametrize("suite", H.SUITES)
+def test_step_kernel_matches_reference_fixtures(torch_gpu, suite):
+    """Per-step launches through fjsp_env_step vs the stored reference traces."""
+    torch = torch_gpu
+    insts, eps, b, actions, T = _batch_for(suite, torch)
+    st0 = b.reset().cpu().numpy()
+    for e, ep in enumerate(eps):
+        H.assert_state_close(st0[e], ep["state0"], "%s ep %d reset" % (suite, e))
+    states = np.zeros((T, len(eps), 20)); rewards = np.zeros((T, len(eps))); dones = np.zeros((T, len(eps)), np.uint8)
+    clocks = np.zeros((T, len(eps)), np.int64); delays = np.zeros((T, len(eps)), np.int64)
+    for t in range(T):
+        s, r, d = b.step(actions[t])
+        rd = b.read()
+        states[t] = s.cpu().numpy(); rewards[t] = r.cpu().numpy(); dones[t] = d.cpu().numpy()
+        clocks[t] = rd["step_time"].cpu().numpy(); delays[t] = rd["delay_time_sum"].cpu().numpy()
+    final = b.read()
+    tend = b.machine_time_end().cpu().numpy()
+    status = final["status"].cpu().numpy()
+    for e, ep in enumerate(eps):
+        Te = ep["T"]
+        tag = "%s episode %d (%s)" % (suite, e, insts[ep["inst"]].name)
+        assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(ep["reward"])), tag + " reward"
+        assert np.array_equal(dones[:Te, e], ep["done"]), tag + " done"
+        assert np.array_equal(clocks[:Te, e], ep["step_time"]), tag + " step_time"
+        assert np.array_equal(delays[:Te, e], ep["delay"]), tag + " delay_time_sum"
+        if "states" in ep:
+            H.assert_state_close(states[:Te, e], ep["states"], tag)
+        H.assert_state_close(states[Te - 1, e], ep["state_last"], tag + " last state")
+        M = insts[ep["inst"]].M
+        assert np.array_equal(tend[e, :M], ep["tend"]), tag + " machine time_end"
+        assert int(final["makespan"][e]) == ep["final"][0] and int(final["delay_time_sum"][e]) == ep["final"][1], tag
+        assert int(final["step_count"][e]) == Te and int(final["done"][e]) == 1
+        # only the "stepped after done" bit may be set (episodes shorter than T keep receiving actions)
+        assert status[e] & ~4 == 0, tag + " status %d" % status[e]
+        assert (status[e] & 4 != 0) == (Te < T)
+
+
+@pytest.mark.parametrize("suite", H.SUITES)
+def test_rollout_kernel_matches_reference_fixtures(torch_gpu, suite):
+    """The fused T-step kernel: chosen (operation, machine) per step, rewards, final attributes."""
+    torch = torch_gpu
+    insts, eps, b, actions, T = _batch_for(suite, torch)
+    b.reset()
+    trace, rewards, state = b.rollout(actions)
+    trace = trace.cpu().numpy(); rewards = rewards.cpu().numpy(); state = state.cpu().numpy()
+    final = b.read()
+    tend = b.machine_time_end().cpu().numpy()
+    for e, ep in enumerate(eps):
+        Te = ep["T"]
+        tag = "%s episode %d (%s)" % (suite, e, insts[ep["inst"]].name)
+        assert np.array_equal(trace[:Te, e, 0], ep["k"]), tag + " chosen operation type"
+        assert np.array_equal(trace[:Te, e, 1], ep["m"]), tag + " chosen machine"
+        assert (trace[Te:, e] == -1).all(), tag
+        assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(ep["reward"])), tag + " reward"
+        assert (rewards[Te:, e] == 0).all()
+        H.assert_state_close(state[e], ep["state_last"], tag + " last state")
+        M = insts[ep["inst"]].M
+        assert np.array_equal(tend[e, :M], ep["tend"]), tag
+        assert int(final["makespan"][e]) == ep["final"][0] and int(final["delay_time_sum"][e]) == ep["final"][1], tag
+        assert int(final["status"][e]) == 0 and int(final["done"][e]) == 1 and int(final["step_count"][e]) == Te
+
+
+def test_full_size_batch_against_oracle_and_invariants(torch_gpu):
+    """BASELINE config 2 at full size: 4096 generated 10x5 instances (seeds 1000+i), random policy.
+
+    Oracle comparison on a sample of envs (the oracle finishes those in seconds) plus
+    size-independent properties on all 4096: one step per operation, rewards telescope to
+    -delay_time_sum, the fused kernel and the per-step kernel agree bit for bit, and an
+    autoreset pass reproduces the first episode (reset is idempotent)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+    N = 4096
+    s = fi.InstanceSet(N).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
+    K = np.array([s.dims(i)["K"] for i in range(N)])
+    T = int(K.max())
+    rs = np.random.RandomState(123)
+    actions_h = np.stack([rs.randint(0, 6, (T, N)), rs.randint(0, 5, (T, N))], 2).astype(np.uint8)
+    actions = torch.from_numpy(actions_h).cuda()
+    b = EnvBatch(s, N, rng_seed=99)
+    st0 = b.reset().clone()
+    states, rewards, dones = [], [], []
+    for t in range(T):
+        st, r, d = b.step(actions[t])
+        states.append(st.clone()); rewards.append(r.clone()); dones.append(d.clone())
+    rewards = torch.stack(rewards).cpu().numpy(); dones = torch.stack(dones).cpu().numpy()
+    states = torch.stack(states).cpu().numpy()
+    fin = {k: v.cpu().numpy() for k, v in b.read().items()}
+    assert (fin["done"] == 1).all() and np.array_equal(fin["step_count"], K)          # one step per operation
+    assert np.array_equal(-rewards.sum(0).astype(np.int64), fin["delay_time_sum"])     # telescoping rewards
+    first_done = dones.argmax(0)
+    assert np.array_equal(first_done + 1, K)
+    assert (fin["status"] & ~4 == 0).all()
+    # fused kernel == per-step kernel on all 4096 envs
+    b2 = EnvBatch(s, N, rng_seed=99)
+    b2.reset()
+    tr, rw, st_last = b2.rollout(actions)
+    fin2 = {k: v.cpu().numpy() for k, v in b2.read().items()}
+    assert np.array_equal(H.bits(rw.cpu().numpy()), H.bits(rewards))
+    for key in ("delay_time_sum", "makespan", "step_time", "step_count", "completion_time"):
+        assert np.array_equal(fin[key], fin2[key]), key
+    last = states[K - 1, np.arange(N)]
+    assert np.array_equal(H.bits(st_last.cpu().numpy()), H.bits(last))
+    # oracle on a sample
+    tr = tr.cpu().numpy()
+    for e in list(range(0, N, 64)):
+        a = s.arrays(e)
+        want = H.play_oracle(a, a.x, actions_h[:, e], b.env_seed(e))
+        Te = want["T"]
+        assert Te == K[e]
+        assert np.array_equal(tr[:Te, e, 0], want["k"]) and np.array_equal(tr[:Te, e, 1], want["m"]), e
+        assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(want["reward"])), e
+        H.assert_state_close(st0[e].cpu().numpy(), want["state0"], "env %d reset" % e)
+        H.assert_state_close(states[:Te, e], want["states"], "env %d" % e)
+        assert fin["makespan"][e] == want["makespan"] and fin["delay_time_sum"][e] == want["delay_time_sum"]
+    # autoreset: a done env is reset inside the next step; reset state must equal the first one.
+    # (the random.choice stream continues across resets, so only deterministic rules are replayed)
+    det = np.stack([np.full((T, N), 2), np.full((T, N), 0)], 2).astype(np.uint8)
+    b3 = EnvBatch(s, N, rng_seed=1)
+    b3.reset()
+    det_d = torch.from_numpy(det).cuda()
+    ep1 = []
+    for t in range(T):
+        st, r, d = b3.step(det_d[t], autoreset=True)
+        ep1.append((st.clone(), r.clone(), d.clone()))
+    # envs with K == T finished exactly at the last step; step again with autoreset -> first step of episode 2
+    st, r, d = b3.step(det_d[0], autoreset=True)
+    idx = np.nonzero(K == T)[0]
+    assert len(idx) > 0
+    assert np.array_equal(H.bits(st.cpu().numpy()[idx]), H.bits(ep1[0][0].cpu().numpy()[idx]))
+    assert np.array_equal(H.bits(r.cpu().numpy()[idx]), H.bits(ep1[0][1].cpu().numpy()[idx]))
+
+
+def test_error_behaviour(torch_gpu):
+    """MyError on undefined rules, error on stepping a finished episode, picklable env."""
+    import pickle
+    from deep_reinforcement_learning_for_fjsp_amd.environments import SO_FJSSP_Environment
+    from deep_reinforcement_learning_for_fjsp_amd.utilities.Utility_Class import MyError
+    env = SO_FJSSP_Environment(use_instance=True, DDT=1.0, M=6, S=1, seed=11)
+    s0 = env.reset()
+    assert s0.shape == (20,) and s0.dtype == np.float64 and s0[0] == 6.0
+    with pytest.raises(MyError):
+        env.step([6, 0])
+    with pytest.raises(MyError):
+        env.step([0, 5])
+    total = 0
+    while not env.done:
+        s, r, d = env.step([2, 0])
+        assert isinstance(r, int)
+        total += r
+    assert -total == env.delay_time_sum and env.reward_sum == total
+    assert max(v.time_end for v in env.machine_dict.values()) >= env.step_time > 0
+    with pytest.raises(ValueError):
+        env.step([2, 0])
+    env2 = pickle.loads(pickle.dumps(env))
+    s1 = env2.reset()
+    assert np.array_equal(H.bits(s1), H.bits(s0))

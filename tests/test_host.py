@@ -1,0 +1,258 @@
+"""CPU: host logic of the product library (no compute kernels are called)."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    """The C-ABI library loads and exports every function include/fjsp_amd.h declares."""
+    from deep_reinforcement_learning_for_fjsp_amd import _capi
+    from deep_reinforcement_learning_for_fjsp_amd._build import LIB_PATH
+    hdr = open(os.path.join(REPO, "include", "fjsp_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fjsp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = C.CDLL(LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _capi.lib().fjsp_abi_version() == 1
+
+
+def test_oracle_is_not_linked_into_the_product(built):
+    """The product library must not contain the oracle (no CPU fallback in the product path)."""
+    from deep_reinforcement_learning_for_fjsp_amd._build import LIB_PATH, PKG_DIR
+    blob = open(LIB_PATH, "rb").read()
+    assert b"fjo_step" not in blob and b"fjo_reset" not in blob
+    for root, _, files in os.walk(PKG_DIR):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "pyoracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    from deep_reinforcement_learning_for_fjsp_amd import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libfjsp_amd.so")
+    with pytest.raises(ImportError):
+        _capi.lib()
+
+
+def test_env_create_without_gpu_or_bad_args_errors(built):
+    """No device / bad arguments -> an error code, never a silent CPU path."""
+    import torch
+    from deep_reinforcement_learning_for_fjsp_amd import _capi, instances as fi
+    s = fi.InstanceSet(1).generate(0, 1, fi.bench_10x5_params())
+    h = C.c_void_p()
+    lib = _capi.lib()
+    # fluid solution missing
+    assert lib.fjsp_env_create(s.handle, 0, 1, 4, 0, 0, 0, C.byref(h)) == -7
+    s.solve_fluid()
+    if not torch.cuda.is_available():
+        assert lib.fjsp_env_create(s.handle, 0, 1, 4, 0, 0, 0, C.byref(h)) == -6
+        assert b"no HIP device" in lib.fjsp_last_error()
+        from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+        with pytest.raises(RuntimeError):
+            EnvBatch(s, 4)
+
+
+def _write_csv(arr, folder):
+    import csv
+    os.makedirs(folder, exist_ok=True)
+    with open(os.path.join(folder, "based_data.csv"), "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["kind_count", "machine_count", "order_count", "DDT"])
+        w.writerow([arr.R, arr.M, arr.S, arr.ddt])
+    koff = np.concatenate(([0], np.cumsum(arr.Jr)))
+    with open(os.path.join(folder, "process_data.csv"), "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["kind", "task", "machine_selectable", "process_time"])
+        for r in range(arr.R):
+            for j in range(int(arr.Jr[r])):
+                k = int(koff[r]) + j
+                ms = tuple(int(m) for m in arr.elig_list[k, :arr.elig_n[k]])
+                w.writerow([r, j, ms, tuple(int(arr.p[k, m]) for m in ms)])
+    with open(os.path.join(folder, "order_data.csv"), "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["order", "time_arrive", "time_delivery", "kind_number"])
+        for s in range(arr.S):
+            w.writerow([s, int(arr.arrive[s]), int(arr.delivery[s]), tuple(int(c) for c in arr.count[s])])
+
+
+def test_csv_loader_roundtrip(built, tmp_path):
+    """Arrays -> reference CSV folder format -> loader gives the arrays back (incl. `\\d+` DDT parsing)."""
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    insts, _, _ = H.load_suite("multijob")
+    for i, a in enumerate(insts):
+        _write_csv(a, str(tmp_path / ("I%d" % i)))
+        b = fi.InstanceSet(1).load_csv(0, str(tmp_path), "I%d" % i).arrays(0)
+        for key in ("Jr", "p", "elig_n", "count", "arrive", "delivery"):
+            assert np.array_equal(getattr(a, key), getattr(b, key)), key
+        for k in range(a.K):
+            assert np.array_equal(a.elig_list[k, :a.elig_n[k]], b.elig_list[k, :b.elig_n[k]])
+        assert b.ddt == float(int(a.ddt))      # "0.5" -> 0, "1.0" -> 1  (SO_DFJSP_instance_read.py:36-40)
+
+
+def test_csv_loader_errors(built, tmp_path):
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd._capi import FjspError
+    with pytest.raises(FjspError) as ei:
+        fi.InstanceSet(1).load_csv(0, str(tmp_path), "missing")
+    assert ei.value.code == -2
+    insts, _, _ = H.load_suite("mk01")
+    _write_csv(insts[0], str(tmp_path / "bad"))
+    with open(str(tmp_path / "bad" / "process_data.csv"), "a") as f:
+        f.write('0,9,"(0,)","(3,)"\n')          # operation numbering gap
+    with pytest.raises(FjspError) as ei:
+        fi.InstanceSet(1).load_csv(0, str(tmp_path), "bad")
+    assert ei.value.code == -3
+
+
+def test_generator_is_seeded_and_in_range(built):
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    prm = fi.bench_10x5_params()
+    s = fi.InstanceSet(3).generate(0, 1000, prm).generate(1, 1000, prm).generate(2, 1001, prm)
+    a, b, c = s.arrays(0), s.arrays(1), s.arrays(2)
+    assert np.array_equal(a.p, b.p) and np.array_equal(a.elig_list, b.elig_list) and not np.array_equal(a.p, c.p)
+    assert a.R == 10 and a.M == 5 and 30 <= a.K <= 50 and (a.count == 1).all()
+    assert a.p.max() <= 20 and ((a.p > 0).sum(1) == a.elig_n).all() and (a.elig_n >= 1).all()
+    # delivery = int(sum_k mean_m p * count * DDT / (2M))  (Instance_generate.py:81-88)
+    mean = np.array([a.p[k, a.elig_list[k, :a.elig_n[k]]].sum() / a.elig_n[k] for k in range(a.K)])
+    acc = 0.0
+    for v in mean:
+        acc = acc + v * 1
+    assert a.delivery[0] == int(acc * 1.0 / 10)
+    # stored synthetic fixtures are exactly generator(seed 1000 + i)
+    insts, _, _ = H.load_suite("synth10x5")
+    g = fi.InstanceSet(len(insts)).generate_range(1000, prm)
+    for i, want in enumerate(insts):
+        got = g.arrays(i)
+        assert np.array_equal(got.p, want.p) and np.array_equal(got.elig_list, want.elig_list), i
+    big = fi.InstanceSet(1).generate(0, 7, fi.reference_generator_params(1.0, 15, 3)).arrays(0)
+    assert 3 <= big.R <= 12 and big.S == 3 and 40 <= big.p[big.p > 0].min() and big.p.max() <= 400
+    assert (big.count >= 5).all() and (big.count <= 50).all() and big.arrive[0] == 0
+
+
+def _lp_highs(a, Q, now):
+    """Independent formulation of class_FJSSP.py:246-280 solved by scipy/HiGHS."""
+    from scipy.optimize import linprog
+    K, M = a.p.shape
+    cols = [(k, m) for k in range(K) for m in range(M) if a.p[k, m] > 0]
+    idx = {km: i for i, km in enumerate(cols)}
+    n = len(cols) + 1
+    A, b = [], []
+    for k in range(K):
+        row = np.zeros(n); row[-1] = 1.0
+        for m in range(M):
+            if a.p[k, m] > 0:
+                row[idx[(k, m)]] = -(1.0 / a.p[k, m]) / Q[k]
+        A.append(row); b.append(0.0)
+    for m in range(M):
+        row = np.zeros(n)
+        for k in range(K):
+            if a.p[k, m] > 0:
+                row[idx[(k, m)]] = 1.0
+        A.append(row); b.append(1.0)
+    koff = np.concatenate(([0], np.cumsum(a.Jr)))
+    for r in range(len(a.Jr)):
+        for j in range(int(a.Jr[r]) - 1):
+            k = int(koff[r]) + j
+            if now[k + 1] == 0:
+                row = np.zeros(n)
+                for m in range(M):
+                    if a.p[k + 1, m] > 0:
+                        row[idx[(k + 1, m)]] += 1.0 / a.p[k + 1, m]
+                    if a.p[k, m] > 0:
+                        row[idx[(k, m)]] -= 1.0 / a.p[k, m]
+                A.append(row); b.append(0.0)
+    c = np.zeros(n); c[-1] = -1.0
+    res = linprog(c, A_ub=np.array(A), b_ub=np.array(b), bounds=[(0, 1)] * len(cols) + [(None, None)], method="highs")
+    assert res.status == 0
+    return -res.fun, np.array(A), np.array(b), idx
+
+
+def test_fluid_lp_is_optimal_and_deterministic(built):
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    cases = []
+    for suite in ("mk01", "multijob"):
+        cases += H.load_suite(suite)[0]
+    cases += H.load_suite("synth10x5")[0][:6]
+    rng = np.random.RandomState(5)
+    for a in cases:
+        koff = np.concatenate(([0], np.cumsum(a.Jr)))
+        states = [(np.repeat(a.count[0], a.Jr).astype(np.int32),
+                   np.array([a.count[0][r] if j == 0 else 0 for r in range(a.R) for j in range(a.Jr[r])], np.int32))]
+        # a mid-episode state: some later stages already hold jobs (constraint :271 switched off there)
+        Q = states[0][0].copy(); now = states[0][1].copy()
+        for r in range(a.R):
+            j = rng.randint(0, a.Jr[r])
+            now[koff[r] + j] += 1
+        states.append((Q, now))
+        for Q, now in states:
+            x, obj = fi.fluid_lp(a.Jr, a.p, Q, now)
+            x2, obj2 = fi.fluid_lp(a.Jr, a.p, Q, now)
+            assert np.array_equal(x, x2) and obj == obj2
+            best, A, b, idx = _lp_highs(a, Q, now)
+            assert abs(best - obj) <= 1e-9 * max(1.0, abs(best)), (a.name, best, obj)
+            v = np.zeros(A.shape[1]); v[-1] = obj
+            for (k, m), i in idx.items():
+                v[i] = x[k, m]
+            assert (A @ v - b).max() < 1e-9 and x.min() >= 0.0 and x.max() <= 1.0
+            assert (x[a.p == 0] == 0).all()
+    # the stored fixture x is what the solver returns today (x is an input of every parity test)
+    a = H.load_suite("mk01")[0][0]
+    s = H.instance_set_from([a]).solve_fluid()
+    assert np.array_equal(s.arrays(0).x, a.x)
+
+
+def test_pyset_emulation_matches_cpython(built):
+    """list(set(a) & set(b)) order for small ints: the oracle's emulation vs this interpreter."""
+    from oracle import pyoracle
+    rnd = random.Random(3)
+    for M in (3, 5, 6, 8, 10, 15, 20, 32, 40, 64):
+        for _ in range(400):
+            idle = sorted(rnd.sample(range(M), rnd.randint(0, M)))
+            elig = rnd.sample(range(M), rnd.randint(1, M))
+            assert pyoracle.pyset_and_list(idle, elig) == list(set(idle) & set(elig)), (idle, elig)
+    # exhaustive over idle subsets for one shuffled eligibility tuple at M = 10
+    elig = [7, 2, 9, 0, 5, 8]
+    for mask in range(1 << 10):
+        idle = [m for m in range(10) if mask >> m & 1]
+        assert pyoracle.pyset_and_list(idle, elig) == list(set(idle) & set(elig))
+
+
+def test_device_pyset_order_matches_cpython(built):
+    """csrc/fjsp_pyset.h (host build of the code machine_select runs on the GPU) vs this interpreter."""
+    from deep_reinforcement_learning_for_fjsp_amd import _capi
+    lib = _capi.lib()
+    out = np.zeros(32, np.int32)
+
+    def order(idle, machines, ascending):
+        mask = 0
+        for m in idle:
+            mask |= 1 << m
+        arr = np.ascontiguousarray(machines, dtype=np.int32)
+        n = lib.fjsp_pyset_and_order(mask, arr.ctypes.data_as(C.c_void_p), len(arr), int(ascending),
+                                     out.ctypes.data_as(C.c_void_p))
+        assert n >= 0
+        return out[:n].tolist()
+
+    rnd = random.Random(7)
+    for M in (2, 5, 6, 8, 9, 10, 15, 20, 32):
+        for _ in range(1500):
+            idle = sorted(rnd.sample(range(M), rnd.randint(0, M)))
+            elig = rnd.sample(range(M), rnd.randint(1, M))
+            assert order(idle, elig, False) == list(set(idle) & set(elig)), (idle, elig)
+            fl = sorted(elig)
+            assert order(idle, fl, True) == list(set(idle) & set(fl)), (idle, fl)
+    for elig in ([7, 2, 9, 0], [8, 0, 16, 24], [9, 1], [31, 7, 15, 23], [12, 4, 20]):
+        for mask in range(1 << 10):
+            idle = [m for m in range(10) if mask >> m & 1] + ([12, 15, 16, 20, 23, 24, 31] if mask & 1 else [])
+            idle = sorted(set(idle))
+            assert order(idle, elig, False) == list(set(idle) & set(elig)), (idle, elig)

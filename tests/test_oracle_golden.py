@@ -1,0 +1,49 @@
+"""CPU: the C oracle reproduces every stored reference trace bit-exactly.
+
+The fixtures were produced by tests/golden/make_golden.py from the reference
+itself (see tests/golden/GENERATION_REPORT.txt); here the oracle replays the
+stored actions on the stored instance arrays + fluid solution.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+@pytest.mark.parametrize("suite", H.SUITES)
+def test_oracle_matches_reference_fixtures(built, suite):
+    insts, eps, _ = H.load_suite(suite)
+    assert eps, "empty fixture"
+    for e, ep in enumerate(eps):
+        a = insts[ep["inst"]]
+        got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"])
+        tag = "%s episode %d (%s)" % (suite, e, a.name)
+        assert got["T"] == ep["T"], tag
+        for key in ("k", "m", "job_r", "job_n", "done", "step_time", "delay"):
+            assert np.array_equal(got[key].astype(np.int64), ep[key].astype(np.int64)), tag + " " + key
+        assert np.array_equal(H.bits(got["reward"]), H.bits(ep["reward"])), tag + " reward"
+        assert np.array_equal(H.bits(got["state0"]), H.bits(ep["state0"])), tag + " reset state"
+        assert np.array_equal(H.states_digest(got["states"]), ep["states_sha256"]), tag + " states digest"
+        assert np.array_equal(H.bits(got["states"][-1]), H.bits(ep["state_last"])), tag + " last state"
+        if "states" in ep:
+            assert np.array_equal(H.bits(got["states"]), H.bits(ep["states"])), tag + " states"
+        assert np.array_equal(got["tend"], ep["tend"]), tag + " machine time_end"
+        assert got["makespan"] == ep["final"][0] and got["delay_time_sum"] == ep["final"][1], tag
+
+
+def test_known_reference_values(built):
+    """Mk01, fixed rule pair (2, 0): the values the reference produced under the product's x."""
+    insts, eps, _ = H.load_suite("mk01")
+    ep = eps[2 * 5 + 0]
+    assert tuple(ep["actions"][0]) == (2, 0)
+    assert ep["T"] == 55                       # one step per operation
+    assert -int(ep["reward"].sum()) == int(ep["final"][1])   # rewards telescope to -delay_time_sum
+    assert int(ep["final"][0]) == int(ep["tend"].max())
+
+
+def test_reward_telescopes_everywhere(built):
+    for suite in H.SUITES:
+        _, eps, _ = H.load_suite(suite)
+        for ep in eps:
+            assert -int(ep["reward"].sum()) == int(ep["final"][1])
+            assert bool(ep["done"][-1]) and not ep["done"][:-1].any()
