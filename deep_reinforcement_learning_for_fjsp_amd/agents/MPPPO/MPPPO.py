@@ -1,0 +1,244 @@
+"""Batched counterpart of the reference's agents/MPPPO/MPPPO.py (on-policy update
+path).  The MLPs, the return normalisation and the
+clipped-PPO update stay in PyTorch-ROCm (MFMA only in the dense GEMMs); rollouts
+come from the HIP environment batch and land in the C-ABI rollout buffer.
+
+What is kept from the reference, by line:
+  ActorNet / CriticNet                 MPPPO.py:31-67   (Linear+ReLU stack, softmax head)
+  pick_action_and_log_prob             :272-284         (Categorical sample, epsilon-random override)
+  calculate_discounted_returns         :301-312         (reverse scan, f32 element arithmetic)
+  normalise to [0,1] then standardise  :258-261         (+1e-8, unbiased std)
+  advantages = G - V(s)                :263
+  ratio / clipped surrogate            :325-352         (exp(new) / (exp(old) + 1e-8), clip 0.2)
+  Adam(lr 3e-4, eps 1e-4), grad-clip 1 :145-147,358-370
+  equalise_policies                    :372-375
+Two defects of the shipped script are fixed rather than replicated (SURVEY.md row
+a21): the critic loss is not detached before backward (:319 makes the critic
+never train), and equalise_policies copies `.data` (:375 `algorithm_means`
+raises AttributeError at the end of the first episode).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn, optim
+from torch.distributions import Categorical
+
+from ..Base_Agent import Base_Agent
+from ... import distributed as fdist
+
+HYPER = {   # utilities/data_structures/Config.py "MP_PPO"
+    "learning_rate": 0.0003, "discount_rate": 0.99, "clip_epsilon": 0.2, "gradient_clipping_norm": 1.0,
+    "learning_iterations_per_round_actor": 10, "learning_iterations_per_round_critic": 10,
+    "epsilon_decay_rate_denominator": 10, "normalized_rewards": True, "standardized_rewards": True, "tau": 0.005,
+}
+
+
+class ActorNet(nn.Module):
+    """MPPPO.py:31-48"""
+
+    def __init__(self, input_size, hidden_size, hidden_layer, output_size):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(input_size, hidden_size), nn.ReLU()])
+        for _ in range(hidden_layer - 1):
+            self.layers.append(nn.Linear(hidden_size, hidden_size))
+            self.layers.append(nn.ReLU())
+        self.layers.append(nn.Linear(hidden_size, output_size))
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return F.softmax(x, dim=-1)
+
+
+class CriticNet(nn.Module):
+    """MPPPO.py:51-67"""
+
+    def __init__(self, input_size, hidden_size, hidden_layer, output_size):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(input_size, hidden_size), nn.ReLU()])
+        for _ in range(hidden_layer - 1):
+            self.layers.append(nn.Linear(hidden_size, hidden_size))
+            self.layers.append(nn.ReLU())
+        self.layers.append(nn.Linear(hidden_size, output_size))
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+# ----------------------------------------------------------------------------- math
+def discounted_returns(rewards, valid, gamma):
+    """MPPPO.py:301-312 for [T, N] f32 tensors: G_t = r_t + gamma * G_{t+1} per env, walking back over
+    valid rows, f32 multiply then f32 add (the reference's tensor-element arithmetic)."""
+    T = rewards.shape[0]
+    g = torch.zeros_like(rewards[0])
+    out = torch.zeros_like(rewards)
+    gam = torch.tensor(gamma, dtype=rewards.dtype, device=rewards.device)
+    for t in range(T - 1, -1, -1):
+        g_new = rewards[t] + gam * g
+        g = torch.where(valid[t] > 0, g_new, g)
+        out[t] = torch.where(valid[t] > 0, g, torch.zeros_like(g))
+    return out
+
+
+def normalise_returns(G, valid, normalized=True, standardized=True):
+    """MPPPO.py:258-261 applied per env (each env's episode is one reference episode)."""
+    m = valid > 0
+    if normalized:
+        big = torch.finfo(G.dtype).max
+        gmin = torch.where(m, G, torch.full_like(G, big)).min(0).values
+        gmax = torch.where(m, G, torch.full_like(G, -big)).max(0).values
+        G = (G - gmin) / (gmax - gmin + 1e-8)
+    if standardized:
+        n = m.sum(0).clamp(min=1).to(G.dtype)
+        mean = (G * m).sum(0) / n
+        var = (((G - mean) ** 2) * m).sum(0) / (n - 1).clamp(min=1)    # torch .std() is unbiased
+        G = (G - mean) / (var.sqrt() + 1e-8)
+    return G * m
+
+
+def actor_loss_terms(new_log_prob, old_log_prob, advantages, clip_epsilon):
+    """MPPPO.py:325-352 per sample (the caller takes -mean over valid samples)."""
+    ratio = torch.exp(new_log_prob) / (torch.exp(old_log_prob) + 1e-8)
+    return torch.min(advantages * ratio, advantages * torch.clamp(ratio, 1.0 - clip_epsilon, 1.0 + clip_epsilon))
+
+
+class PPOLearner(object):
+    """Networks + optimisers + one clipped-PPO learning round over a [T, N] rollout.
+
+    Data parallel over env shards: every rank holds the same parameters, computes the
+    gradient of (sum of its samples' losses) / (global sample count), the flat gradient
+    bucket is all-reduced (ONE RCCL call per optimiser step) and clipped
+    after the reduction so all ranks apply the identical update."""
+
+    def __init__(self, state_size, action_size, hidden_size=128, hidden_layer=2, critic_hidden_layer=2,
+                 device="cpu", seed=0, hyper=None, train_critic=True):
+        self.hp = dict(HYPER)
+        self.hp.update(hyper or {})
+        self.device = torch.device(device)
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(seed)            # identical initial parameters on every rank
+        self.actor_new = ActorNet(state_size, hidden_size, hidden_layer, action_size).to(self.device)
+        self.actor_old = ActorNet(state_size, hidden_size, hidden_layer, action_size).to(self.device)
+        self.critic = CriticNet(state_size, hidden_size, critic_hidden_layer, 1).to(self.device)
+        torch.random.set_rng_state(gen_state)
+        Base_Agent.copy_model_over_dict(self.actor_new, self.actor_old)
+        self.actor_optimizer = optim.Adam(self.actor_new.parameters(), lr=self.hp["learning_rate"], eps=1e-4)
+        self.critic_optimizer = optim.Adam(self.critic.parameters(), lr=self.hp["learning_rate"], eps=1e-4)
+        self.action_size = action_size
+        self.train_critic = train_critic
+        self.actor_bucket = fdist.FlatGradBucket(self.actor_new.parameters())
+        self.critic_bucket = fdist.FlatGradBucket(self.critic.parameters())
+
+    @torch.no_grad()
+    def act(self, states, epsilon=0.0, generator=None):
+        """pick_action_and_log_prob (:272-284) for a batch of states [N, S] (f32)."""
+        probs = self.actor_new(states)
+        dist = Categorical(probs)
+        action = dist.sample()
+        if epsilon > 0.0:
+            u = torch.rand(action.shape, device=action.device, generator=generator)
+            rnd = torch.randint(0, self.action_size, action.shape, device=action.device, generator=generator)
+            action = torch.where(u <= epsilon, rnd, action)
+        return action, dist.log_prob(action)
+
+    def learn(self, states, actions, old_log_prob, returns, valid):
+        """critic_actor_learn (:314-323) on flattened [T*N] samples; returns (critic_loss, actor_loss)."""
+        hp = self.hp
+        S = states.shape[-1]
+        states = states.reshape(-1, S)
+        actions = actions.reshape(-1)
+        old_log_prob = old_log_prob.reshape(-1).detach()
+        returns = returns.reshape(-1).detach()
+        m = (valid.reshape(-1) > 0).to(states.dtype)
+        count = fdist.all_reduce_scalar_sum(m.sum())          # global number of samples
+        with torch.no_grad():
+            advantages = returns - self.critic(states).squeeze(1)                       # :263
+        c_loss = a_loss = None
+        for _ in range(hp["learning_iterations_per_round_critic"]):
+            critic_out = self.critic(states).squeeze(1)
+            c_loss = (((critic_out - returns) ** 2) * m).sum() / count                 # F.mse_loss, :318
+            if self.train_critic:
+                self.critic_optimizer.zero_grad()
+                c_loss.backward()
+                self.critic_bucket.all_reduce()
+                torch.nn.utils.clip_grad_norm_(self.critic.parameters(), hp["gradient_clipping_norm"])
+                self.critic_optimizer.step()
+            new_log_prob = Categorical(self.actor_new(states)).log_prob(actions)
+            terms = actor_loss_terms(new_log_prob, old_log_prob, advantages, hp["clip_epsilon"])
+            a_loss = -(terms * m).sum() / count                                         # -torch.mean(...), :351
+            self.actor_optimizer.zero_grad()
+            a_loss.backward()
+            self.actor_bucket.all_reduce()
+            torch.nn.utils.clip_grad_norm_(self.actor_new.parameters(), hp["gradient_clipping_norm"])
+            self.actor_optimizer.step()
+        self.equalise_policies()
+        return float(c_loss.detach()), float(a_loss.detach())
+
+    def equalise_policies(self):
+        """:372-375 with the AttributeError fixed."""
+        for old_param, new_param in zip(self.actor_old.parameters(), self.actor_new.parameters()):
+            old_param.data.copy_(new_param.data)
+
+
+class PPO(Base_Agent):
+    """The agent loop of MPPPO.py:230-270 over a batch of environments.
+
+    `environment` is a BatchedSOFJSSP; the flat action a in [0, 30) is the rule pair
+    (a // 5, a % 5) of SO_FJSSP's [6, 5] action space."""
+
+    def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None):
+        super().__init__()
+        from .Buffer import RolloutBuffer
+        self.environment = environment
+        self.device = environment.device
+        self.state_size = environment.state_size
+        self.action_size = environment.actions_size[0] * environment.actions_size[1]
+        self.learner = PPOLearner(self.state_size, self.action_size, hidden_size, hidden_layer, hidden_layer,
+                                  device=self.device, seed=seed, hyper=hyper)
+        self.hyper_parameters = self.learner.hp
+        self.max_steps = max_steps
+        self.memory = None
+        self._RolloutBuffer = RolloutBuffer
+        self.global_step_number = 0
+
+    def run_one_policy_network(self, exploration=None):
+        """One batched episode + one learning round. Returns (mean delay_time_sum, mean makespan)."""
+        env, N = self.environment, self.environment.N
+        hp = self.hyper_parameters
+        if exploration is None:                                                         # :240-241
+            exploration = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])
+        state64 = env.reset().clone()
+        T = self.max_steps or 64
+        if self.memory is None or self.memory.T < T:
+            self.memory = self._RolloutBuffer(T, N, self.state_size, device=self.device.index or 0)
+        self.memory.clear()
+        old_log_prob = torch.zeros(T, N, device=self.device)
+        done = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        act_pair = torch.zeros(N, 2, dtype=torch.uint8, device=self.device)
+        t = 0
+        while t < T:
+            active = (done == 0).to(torch.uint8)
+            a, lp = self.learner.act(state64.float(), exploration)
+            act_pair[:, 0] = (a // env.actions_size[1]).to(torch.uint8)
+            act_pair[:, 1] = (a % env.actions_size[1]).to(torch.uint8)
+            old_log_prob[t] = lp
+            nxt, rew, dn = env.step(act_pair)
+            # the flat action index is what the policy is trained on
+            self.memory.add_experience(state64, act_pair, rew, nxt, dn, active)
+            self.memory.actions[t, :, 0] = a.float()
+            state64 = nxt.clone()
+            done = dn.clone()
+            t += 1
+            self.global_step_number += int(N)
+            if t % 8 == 0 and bool((done != 0).all()):
+                break
+        n = len(self.memory)
+        states, actions, rewards, _, _ = self.memory.sample()
+        valid = self.memory.valid[:n]
+        G = self.memory.compute_returns(hp["discount_rate"])
+        G = normalise_returns(G, valid, hp["normalized_rewards"], hp["standardized_rewards"])
+        losses = self.learner.learn(states, actions[..., 0].long(), old_log_prob[:n], G, valid)
+        self.episode_number += 1
+        r = env.read()
+        return float(r["delay_time_sum"].double().mean()), float(r["makespan"].double().mean()), losses

@@ -1,0 +1,95 @@
+"""Multi-GPU plumbing: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm, over xGMI inside a node).
+
+The environment path shards with no collective at all: env ids [g*N/G, (g+1)*N/G)
+live on GPU g and every instance is a pure function of its global env id
+(SURVEY.md 8e).  The only exchange step of the training path is ONE all-reduce
+of one flat f32 gradient bucket per optimiser step (actor 2x128: 23 070 floats,
+critic: 19 329 floats -> latency-bound messages far below the per-link xGMI
+rate, so everything is bucketed into a single call per network and clipping
+happens after the reduction).  The reference's only parallel mechanism is the
+asynchronous A3C gradient queue (agents/HMPSAC/A3C_v5.1.py:125-187); this
+replaces it for the on-policy path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def rank():
+    return dist.get_rank() if is_distributed() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+
+
+def shard_range(n_total, r=None, w=None):
+    """Global env ids of rank r: a contiguous range, sizes differ by at most one."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, rem = divmod(n_total, w)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)
+
+
+def all_reduce_scalar_sum(x):
+    """Sum of a 0-dim tensor over ranks (the global sample count of a learning round)."""
+    if not is_distributed():
+        return x
+    y = x.detach().clone().reshape(1)
+    dist.all_reduce(y, op=dist.ReduceOp.SUM)
+    return y[0]
+
+
+class FlatGradBucket(object):
+    """One contiguous f32 buffer holding all gradients of a network; `all_reduce()` copies the
+    gradients in, issues ONE all-reduce (sum) and copies the result back."""
+
+    def __init__(self, parameters):
+        self.params = [p for p in parameters if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def all_reduce(self):
+        if not is_distributed():
+            return
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
