@@ -2,10 +2,18 @@
 //
 // One WAVEFRONT owns one environment.  Lane l of chunk c owns operation type
 // k = 64*c + l (r-major, kind_task_tuple order); lanes 0..M-1 double as the
-// machine lanes.  All per-k arrays are therefore stored as rows of KP = 64*KC
-// entries so a wave reads each row with one coalesced load per chunk, and the
-// (machine x op) matrices are stored machine-major: row m = KP contiguous
-// entries (DESIGN.md section "HBM layout").
+// machine lanes.
+//
+// Two slabs, one hipMalloc each:
+//   * the INSTANCE slab: one contiguous record per problem instance (static,
+//     shared by every environment that plays it);
+//   * the ENV slab: one contiguous record per environment (dynamic state).
+// Inside a record every per-k array is a row of KP = 64*KC entries (one
+// coalesced load per chunk) and every (machine x op) matrix is machine-major
+// (row m = KP contiguous entries).  A wave therefore touches two address
+// ranges per step -- its instance record and its own env record -- instead of
+// a dozen unrelated arrays (fewer TLB entries and DRAM pages per wave), and all
+// of its start-up loads can be issued before the first wait.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -42,32 +50,48 @@ static_assert(sizeof(EnvScalars) == 18 * 8, "EnvScalars must be 18 words");
 
 struct InstHeader { int32_t K, M, R, njobs; };
 
+// byte offsets inside the two record types
+struct Layout {
+    // instance record: InstHeader at 0
+    uint32_t i_stride;
+    uint32_t i_kA;      // u32[KP]  first job of the kind (16) | jobs of the kind (16)
+    uint32_t i_kB;      // u32[KP]  stage j (8) | J_r (8) | kind r (8) | flags (8): 1 = last stage, 2 = valid
+    uint32_t i_elig;    // u32[KP]  machine_rj_dict[(r,j)] as a bit mask
+    uint32_t i_fmask;   // u32[KP]  fluid_machine_list as a bit mask (x != 0)           [written by fluid_tables_kernel]
+    uint32_t i_f4;      // u32[KP]  first four machines of machine_rj_dict[(r,j)] in FILE order, 8 bit each
+    uint32_t i_rsum;    // f64[KP]  fluid_rate_sum                                       [fluid_tables_kernel]
+    uint32_t i_tsum;    // f64[KP]  fluid_time_sum                                       [fluid_tables_kernel]
+    uint32_t i_due;     // i32[JP]  job.due_date
+    uint32_t i_jinfo;   // u32[JP]  k of the job's stage 0 (16) | J_r (8)
+    uint32_t i_p;       // u16[MP][KP] time_mrj_dict, 0 = ineligible
+    uint32_t i_x;       // f64[MP][KP] fluid solution (INPUT)
+    uint32_t i_rate;    // f64[MP][KP] fluid_process_rate_rj_dict                        [fluid_tables_kernel]
+    uint32_t i_arr;     // f64[MP][KP] fluid_unprocessed_rj_arrival_dict                 [fluid_tables_kernel]
+    uint32_t i_ss;      // f64[8]   static state (MO variant)
+    // env record: EnvScalars at 0
+    uint32_t e_stride;
+    uint32_t e_tend;    // i32[MP]  machine.time_end
+    uint32_t e_mjob;    // i32[MP]  machine.job_object (job index)
+    uint32_t e_jst;     // u32[JP]  job state words
+    uint32_t e_un;      // f64[MP][KP] machine.unprocessed_rj_dict
+};
+
 struct DevBatch {
     int32_t N, n_inst, KC, KP, MP, JP, variant, n_obs, n_static, state_size;
     uint64_t rng_seed;
-    // ---- static, per instance -------------------------------------------------
-    const InstHeader *ihdr;   // [n_inst]
-    const uint32_t *kinfoA;   // [n_inst][KP]  first job of the kind (16) | jobs of the kind (16)
-    const uint32_t *kinfoB;   // [n_inst][KP]  stage j (8) | J_r (8) | kind r (8) | flags (8): 1 = last stage, 2 = valid
-    const uint32_t *elig;     // [n_inst][KP]  machine_rj_dict[(r,j)] as a bitmask
-    uint32_t *fmask;          // [n_inst][KP]  fluid_machine_list as a bitmask (x != 0)
-    const uint32_t *efirst4;  // [n_inst][KP]  first four machines of machine_rj_dict[(r,j)] in FILE order (8 bit each)
-    const uint16_t *p;        // [n_inst][MP][KP] time_mrj_dict, 0 = ineligible
-    const double *x;          // [n_inst][MP][KP] fluid solution (INPUT)
-    double *rate;             // [n_inst][MP][KP] fluid_process_rate_rj_dict
-    double *arr;              // [n_inst][MP][KP] fluid_unprocessed_rj_arrival_dict
-    double *rate_sum;         // [n_inst][KP]     fluid_rate_sum
-    double *time_sum;         // [n_inst][KP]     fluid_time_sum
-    const int32_t *due;       // [n_inst][JP]     job.due_date
-    const uint32_t *jinfo;    // [n_inst][JP]     k of the job's stage 0 (16) | J_r (8)
-    const double *sstate;     // [n_inst][8]      static state (MO variant)
-    // ---- dynamic, per environment ---------------------------------------------
-    EnvScalars *scal;         // [N]
-    int32_t *tend;            // [N][MP]  machine.time_end
-    int32_t *mjob;            // [N][MP]  machine.job_object (job index)
-    uint32_t *jst;            // [N][JP]  job state words
-    double *un;               // [N][MP][KP] machine.unprocessed_rj_dict
+    unsigned char *inst;     // [n_inst] instance records
+    unsigned char *envs;     // [N] env records
+    Layout L;
 };
+
+template <class T>
+__host__ __device__ inline T *inst_ptr(const DevBatch &b, int inst, uint32_t off) {
+    return reinterpret_cast<T *>(b.inst + (size_t)inst * b.L.i_stride + off);
+}
+template <class T>
+__host__ __device__ inline T *env_ptr(const DevBatch &b, int env, uint32_t off) {
+    return reinterpret_cast<T *>(b.envs + (size_t)env * b.L.e_stride + off);
+}
 
 // kernel launchers (fjsp_kernels.hip); all asynchronous on `st`, 0 = launched
 int launch_fluid_tables(const DevBatch &b, hipStream_t st);

@@ -92,6 +92,11 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         if (in.M > kMaxM) { set_error("more than 32 machines"); return FJSP_E_UNSUPPORTED; }
         const int nj = in.jobs_of_order(0);
         if (nj > 65535) { set_error("more than 65535 jobs"); return FJSP_E_UNSUPPORTED; }
+        {
+            long ntasks = 0;
+            for (int r = 0; r < in.R; ++r) ntasks += (long)in.count[r] * in.Jr[r];
+            if (ntasks > 65535) { set_error("more than 65535 operations in one order"); return FJSP_E_UNSUPPORTED; }
+        }
         for (int r = 0; r < in.R; ++r)
             if (in.Jr[r] > 255) { set_error("more than 255 operations in a kind"); return FJSP_E_UNSUPPORTED; }
         for (int v : in.p)
@@ -119,101 +124,112 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.n_static = variant == FJSP_VARIANT_SO_FJSSP ? 0 : 7;
     b.state_size = b.n_static + 2 * b.n_obs;
     b.rng_seed = rng_seed;
-    const size_t KP = (size_t)b.KP, MP = (size_t)b.MP, JP = (size_t)b.JP, NI = (size_t)n_inst;
-
-    std::vector<InstHeader> ihdr(NI);
-    std::vector<uint32_t> kA(NI * KP, 0), kB(NI * KP, 0), elig(NI * KP, 0), first4(NI * KP, 0), jinfo(NI * JP, 0);
-    std::vector<uint16_t> p(NI * MP * KP, 0);
-    std::vector<double> x(NI * MP * KP, 0.0), sstate(NI * 8, 0.0);
-    std::vector<int32_t> due(NI * JP, 0);
+    const size_t KP = (size_t)b.KP, MP = (size_t)b.MP, JP = (size_t)b.JP, NI = (size_t)n_inst, N = (size_t)n_envs;
+    // ---- record layouts (fjsp_device.h)
+    Layout &L = b.L;
+    {
+        size_t o = 64;                                   // InstHeader, padded
+        auto take = [&](size_t bytes, size_t align) { o = (o + align - 1) / align * align; size_t at = o; o += bytes; return (uint32_t)at; };
+        L.i_kA = take(KP * 4, 4); L.i_kB = take(KP * 4, 4); L.i_elig = take(KP * 4, 4); L.i_fmask = take(KP * 4, 4);
+        L.i_f4 = take(KP * 4, 4); L.i_rsum = take(KP * 8, 8); L.i_tsum = take(KP * 8, 8);
+        L.i_due = take(JP * 4, 4); L.i_jinfo = take(JP * 4, 4); L.i_p = take(MP * KP * 2, 4);
+        L.i_x = take(MP * KP * 8, 8); L.i_rate = take(MP * KP * 8, 8); L.i_arr = take(MP * KP * 8, 8);
+        L.i_ss = take(64, 8);
+        L.i_stride = (uint32_t)((o + 255) / 256 * 256);
+        o = 192;                                         // EnvScalars (144 B), padded
+        L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(MP * KP * 8, 8);
+        L.e_stride = (uint32_t)((o + 255) / 256 * 256);
+    }
+    std::vector<unsigned char> islab(NI * L.i_stride, 0);
+    auto ip = [&](size_t i, uint32_t off) { return islab.data() + i * L.i_stride + off; };
     double bytes_acc = 0.0;
     for (size_t i = 0; i < NI; ++i) {
         const Instance &in = s->v[(size_t)first + i];
         const int nj = in.jobs_of_order(0);
-        ihdr[i] = InstHeader{in.K, in.M, in.R, nj};
+        *reinterpret_cast<InstHeader *>(ip(i, 0)) = InstHeader{in.K, in.M, in.R, nj};
         e->inst_K.push_back(in.K); e->inst_M.push_back(in.M);
+        uint32_t *kA = reinterpret_cast<uint32_t *>(ip(i, L.i_kA)), *kB = reinterpret_cast<uint32_t *>(ip(i, L.i_kB));
+        uint32_t *elig = reinterpret_cast<uint32_t *>(ip(i, L.i_elig)), *first4 = reinterpret_cast<uint32_t *>(ip(i, L.i_f4));
+        uint32_t *jinfo = reinterpret_cast<uint32_t *>(ip(i, L.i_jinfo));
+        int32_t *due = reinterpret_cast<int32_t *>(ip(i, L.i_due));
+        uint16_t *p = reinterpret_cast<uint16_t *>(ip(i, L.i_p));
+        double *x = reinterpret_cast<double *>(ip(i, L.i_x));
         int jbeg = 0;
         for (int r = 0; r < in.R; ++r) {
             const int cnt = in.count[r];
             // class_FJSSP.py:214-218: r_due = round(delivery * J_r / N_r); due(n) = round(r_due * n / N_r)
             const long r_due = py_round((double)((long)in.delivery[0] * in.Jr[r]) / (double)cnt);
             for (int n = 0; n < cnt; ++n) {
-                due[i * JP + jbeg + n] = (int32_t)py_round((double)(r_due * n) / (double)cnt);
-                jinfo[i * JP + jbeg + n] = (uint32_t)in.koff[r] | ((uint32_t)in.Jr[r] << 16);
+                due[jbeg + n] = (int32_t)py_round((double)(r_due * n) / (double)cnt);
+                jinfo[jbeg + n] = (uint32_t)in.koff[r] | ((uint32_t)in.Jr[r] << 16);
             }
             for (int j = 0; j < in.Jr[r]; ++j) {
                 const int k = in.koff[r] + j;
-                kA[i * KP + k] = (uint32_t)jbeg | ((uint32_t)cnt << 16);
-                kB[i * KP + k] = (uint32_t)j | ((uint32_t)in.Jr[r] << 8) | ((uint32_t)(r & 0xFF) << 16) |
-                                 ((uint32_t)((j == in.Jr[r] - 1 ? 1u : 0u) | 2u) << 24);
+                kA[k] = (uint32_t)jbeg | ((uint32_t)cnt << 16);
+                kB[k] = (uint32_t)j | ((uint32_t)in.Jr[r] << 8) | ((uint32_t)(r & 0xFF) << 16) |
+                        ((uint32_t)((j == in.Jr[r] - 1 ? 1u : 0u) | 2u) << 24);
                 uint32_t em = 0;
                 for (int m = 0; m < in.M; ++m) {
                     const int pv = in.p[(size_t)k * in.M + m];
                     if (pv > 0) em |= 1u << m;
-                    p[(i * MP + m) * KP + k] = (uint16_t)pv;
-                    x[(i * MP + m) * KP + k] = in.x[(size_t)k * in.M + m];
+                    p[(size_t)m * KP + k] = (uint16_t)pv;
+                    x[(size_t)m * KP + k] = in.x[(size_t)k * in.M + m];
                 }
-                elig[i * KP + k] = em;
+                elig[k] = em;
                 uint32_t f4 = 0;
                 for (int q = 0; q < in.elig_n[k] && q < 4; ++q) f4 |= (uint32_t)in.elig_list[(size_t)k * in.M + q] << (8 * q);
-                first4[i * KP + k] = f4;
+                first4[k] = f4;
             }
             jbeg += cnt;
         }
         if (variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
-            // MO_FJSSP_discretes.py:55-64 static_state_extract (math.pow(v, 2) is libm pow on the host)
+            // MO_FJSSP_discretes.py:55-64 static_state_extract
             long ns = 0, js = 0;
             for (int r = 0; r < in.R; ++r) { ns += in.count[r]; js += in.Jr[r]; }
             const double N_ave = (double)ns / (double)in.R, J_ave = (double)js / (double)in.R;
             double a = 0.0, c2 = 0.0;
             for (int r = 0; r < in.R; ++r) a = a + std::pow((double)in.count[r] - N_ave, 2.0);
             for (int r = 0; r < in.R; ++r) c2 = c2 + std::pow((double)in.Jr[r] - J_ave, 2.0);
-            double *ss = &sstate[i * 8];
+            double *ss = reinterpret_cast<double *>(ip(i, L.i_ss));
             ss[0] = in.ddt; ss[1] = (double)in.M; ss[2] = (double)in.R; ss[3] = N_ave;
             ss[4] = std::sqrt(a / (double)in.R); ss[5] = J_ave; ss[6] = std::sqrt(c2 / (double)in.R);
         }
         // algorithmic HBM bytes of one env-step (DESIGN.md "bytes per env-step"):
-        //   static per-k rows (kinfoA/B, elig, fmask u32; rate_sum, time_sum f64)      K * 32
-        //   job table read (due, jinfo, jst) + jst write-back                           njobs * 16
-        //   machine lanes tend/mjob read + write                                        M * 16
-        //   EnvScalars read + write                                                     2 * 144
-        //   column gather at k_sel (p u16, un/arr/rate f64) + un read-modify-write      M * 26 + 8
-        //   actions in, state/reward/done out                                           2 + S*8 + 8 + 1
-        bytes_acc += in.K * 32.0 + nj * 16.0 + in.M * 16.0 + 288.0 + in.M * 26.0 + 8.0 + 2.0 + b.state_size * 8.0 + 9.0;
+        //   static per-k rows (kinfoA/B, elig, fmask, first4 u32; rate_sum, time_sum f64)  K * 36
+        //   job table read (due, jinfo, jst) + jst write-back                               njobs * 16
+        //   machine lanes tend/mjob read + write                                            M * 16
+        //   instance header + EnvScalars read + write                                       16 + 2 * 144
+        //   column gather at k_sel (p u16, un/arr/rate f64) + un write                      M * 26 + 8
+        //   actions in, state/reward/done out                                               2 + S*8 + 8 + 1
+        bytes_acc += in.K * 36.0 + nj * 16.0 + in.M * 16.0 + 304.0 + in.M * 26.0 + 8.0 + 2.0 + b.state_size * 8.0 + 9.0;
     }
     e->step_bytes = (int64_t)(bytes_acc / (double)NI + 0.5);
 
-    int rc = FJSP_OK;
-    InstHeader *d_ihdr = nullptr; uint32_t *d_kA = nullptr, *d_kB = nullptr, *d_elig = nullptr, *d_jinfo = nullptr, *d_f4 = nullptr;
-    uint16_t *d_p = nullptr; double *d_x = nullptr, *d_ss = nullptr; int32_t *d_due = nullptr;
-#define TRY(call) do { rc = (call); if (rc != FJSP_OK) { fjsp_env_destroy(e); return rc; } } while (0)
-    TRY(upload(e, ihdr, &d_ihdr)); TRY(upload(e, kA, &d_kA)); TRY(upload(e, kB, &d_kB)); TRY(upload(e, elig, &d_elig));
-    TRY(upload(e, jinfo, &d_jinfo)); TRY(upload(e, p, &d_p)); TRY(upload(e, x, &d_x)); TRY(upload(e, sstate, &d_ss));
-    TRY(upload(e, due, &d_due)); TRY(upload(e, first4, &d_f4));
-    b.ihdr = d_ihdr; b.kinfoA = d_kA; b.kinfoB = d_kB; b.elig = d_elig; b.jinfo = d_jinfo; b.p = d_p; b.x = d_x;
-    b.sstate = d_ss; b.due = d_due; b.efirst4 = d_f4;
-    TRY(dalloc(e, NI * KP, &b.fmask));
-    TRY(dalloc(e, NI * MP * KP, &b.rate)); TRY(dalloc(e, NI * MP * KP, &b.arr));
-    TRY(dalloc(e, NI * KP, &b.rate_sum)); TRY(dalloc(e, NI * KP, &b.time_sum));
-    const size_t N = (size_t)n_envs;
-    TRY(dalloc(e, N, &b.scal)); TRY(dalloc(e, N * MP, &b.tend)); TRY(dalloc(e, N * MP, &b.mjob));
-    TRY(dalloc(e, N * JP, &b.jst)); TRY(dalloc(e, N * MP * KP, &b.un));
-    TRY(dalloc(e, N, &e->d_done_scratch));
-#undef TRY
+    {
+        void *pi = nullptr, *pe = nullptr;
+        if (!hip_ok(hipMalloc(&pi, islab.size()), "hipMalloc instance slab")) { delete e; return FJSP_E_HIP; }
+        e->allocs.push_back(pi);
+        if (!hip_ok(hipMalloc(&pe, N * L.e_stride), "hipMalloc env slab")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
+        e->allocs.push_back(pe);
+        void *pd = nullptr;
+        if (!hip_ok(hipMalloc(&pd, N + 16), "hipMalloc scratch")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
+        e->allocs.push_back(pd);
+        e->d_done_scratch = reinterpret_cast<uint8_t *>(pd);
+        b.inst = reinterpret_cast<unsigned char *>(pi);
+        b.envs = reinterpret_cast<unsigned char *>(pe);
+        // every env starts done so that step() before reset() is flagged, like the
+        // reference's uninitialised object would fail
+        std::vector<unsigned char> eslab(N * L.e_stride, 0);
+        for (size_t q = 0; q < N; ++q) reinterpret_cast<EnvScalars *>(eslab.data() + q * L.e_stride)->done = 1;
+        if (!hip_ok(hipMemcpy(pi, islab.data(), islab.size(), hipMemcpyHostToDevice), "upload instance slab") ||
+            !hip_ok(hipMemcpy(pe, eslab.data(), eslab.size(), hipMemcpyHostToDevice), "upload env slab")) {
+            fjsp_env_destroy(e); return FJSP_E_HIP;
+        }
+    }
     if (launch_fluid_tables(b, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
         set_error("fluid_tables_kernel launch failed");
         fjsp_env_destroy(e);
         return FJSP_E_HIP;
-    }
-    // every env starts done so that step() before reset() is flagged, like the
-    // reference's uninitialised object would fail
-    {
-        std::vector<EnvScalars> init(N);
-        std::memset(init.data(), 0, N * sizeof(EnvScalars));
-        for (auto &sc : init) sc.done = 1;
-        if (hipMemcpy(b.scal, init.data(), N * sizeof(EnvScalars), hipMemcpyHostToDevice) != hipSuccess) {
-            set_error("scalars upload failed"); fjsp_env_destroy(e); return FJSP_E_HIP;
-        }
     }
     *out = e;
     return FJSP_OK;
@@ -287,8 +303,8 @@ int fjsp_env_read(fjsp_env *e, int64_t *d_delay_time_sum, int32_t *d_makespan, i
 int fjsp_env_machine_time_end(fjsp_env *e, int32_t *d_tend, int32_t m_stride, void *stream) {
     if (!e || !d_tend || m_stride < e->b.MP) { set_error("fjsp_env_machine_time_end: bad arguments"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
-    HIP_TRY(hipMemcpy2DAsync(d_tend, (size_t)m_stride * 4, e->b.tend, (size_t)e->b.MP * 4, (size_t)e->b.MP * 4,
-                             (size_t)e->b.N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpy2DAsync(d_tend, (size_t)m_stride * 4, e->b.envs + e->b.L.e_tend, (size_t)e->b.L.e_stride,
+                             (size_t)e->b.MP * 4, (size_t)e->b.N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FJSP_OK;
 }
 
@@ -313,10 +329,11 @@ int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
     const size_t KP = (size_t)e->b.KP, MP = (size_t)e->b.MP;
     std::vector<double> rate(MP * KP), arr(MP * KP), rs(KP), ts(KP);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(rate.data(), e->b.rate + (size_t)inst * MP * KP, MP * KP * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(arr.data(), e->b.arr + (size_t)inst * MP * KP, MP * KP * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(rs.data(), e->b.rate_sum + (size_t)inst * KP, KP * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ts.data(), e->b.time_sum + (size_t)inst * KP, KP * 8, hipMemcpyDeviceToHost));
+    const unsigned char *rec = e->b.inst + (size_t)inst * e->b.L.i_stride;
+    HIP_TRY(hipMemcpy(rate.data(), rec + e->b.L.i_rate, MP * KP * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(arr.data(), rec + e->b.L.i_arr, MP * KP * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rs.data(), rec + e->b.L.i_rsum, KP * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ts.data(), rec + e->b.L.i_tsum, KP * 8, hipMemcpyDeviceToHost));
     for (int k = 0; k < K; ++k) {
         for (int m = 0; m < M; ++m) {
             if (h_rate) h_rate[(size_t)k * M + m] = rate[(size_t)m * KP + k];

@@ -9,6 +9,10 @@
 //   * the job table (state word, due date, kind info) of the environment is
 //     staged in a wave-private LDS slice; the fused rollout kernel also keeps
 //     the machine x op "unprocessed" matrix there;
+//   * static data comes from ONE record per instance and dynamic state from ONE
+//     record per environment (fjsp_device.h), and every start-up load is issued
+//     before the first wait, so a step costs two dependent memory round trips
+//     (state in, column gather at the chosen operation) instead of a chain;
 //   * next-event selection is a DPP min-reduction over the machine lanes,
 //     availability sets are 64-bit ballots, rule argmax/argmin walk the ballot
 //     in index order with readlane so the reference's "first extremum wins"
@@ -103,10 +107,10 @@ struct W {
     long long tard_done, delay_sum;
     uint64_t env_seed;
     // lane = operation type
-    uint32_t kA[KC], kB[KC], elig[KC], fmask[KC];
+    uint32_t kA[KC], kB[KC], elig[KC], fmask[KC], first4[KC];
     double rate_sum[KC], time_sum[KC];
     int nun[KC], cnt_a[KC], cnt_e[KC], max_a[KC], fifo_cnt[KC], head_job[KC], due_min[KC], tard[KC];
-    double max_e[KC], urg[KC];
+    double max_e[KC], sum_e[KC];
     // lane = machine
     int tend_m, mjob_m;
     // lane i < 10: previous observation
@@ -115,59 +119,84 @@ struct W {
     uint32_t *jstL;
     int32_t *dueL;
     uint32_t *jinfoL;
-    double *scrL;   // 16 doubles of scratch
-    double *unp;    // unprocessed_rj matrix [MP][KP]: LDS slice (rollout) or the HBM rows (step)
-    // static rows of this instance
+    double *scrL;   // 16 doubles: the observation being assembled
+    double *frL, *grL, *tdL;   // serial-sum operands: finish_rate[KP], gap_rate[KP], time_end[32]
+    double *unp;    // unprocessed_rj matrix [MP][KP]: LDS slice (rollout) or the env record's rows (step)
+    // rows of this instance / env record
     const uint16_t *p_i;
     const double *rate_i, *arr_i;
+    unsigned char *er;
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, bool un_lds) {
-    return (size_t)JP * 12 + 16 * 8 + (un_lds ? (size_t)MP * KP * 8 : 0);
+    return (size_t)(16 + 2 * KP + 32) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 12;
 }
 
+// Bind the wave to its records and bring the environment in.  All loads below are
+// independent of each other (bounds come from the kernel arguments, not from the
+// instance header), so they are in flight together: one memory round trip.
 template <int KC>
-__device__ __forceinline__ void bind(W<KC> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds) {
+__device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
+                                         bool load_state) {
     w.b = b;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = env % b->n_inst;
-    const InstHeader h = b->ihdr[w.inst];
-    w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
-    w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
     const int JP = b->JP, KP = b->KP, MP = b->MP;
-    // LDS carve: [scratch 16 f64][un (optional)][jst][due][jinfo]
+    const Layout &L = b->L;
+    const unsigned char *ir = b->inst + (size_t)w.inst * L.i_stride;
+    unsigned char *er = b->envs + (size_t)env * L.e_stride;
+    w.er = er;
+    // LDS carve: [obs 16][fr KP][gr KP][td 32][un (optional)][jst][due][jinfo]
     w.scrL = reinterpret_cast<double *>(lds);
-    unsigned char *q = lds + 16 * 8;
+    w.frL = w.scrL + 16; w.grL = w.frL + KP; w.tdL = w.grL + KP;
+    unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + 32);
     if (un_lds) { w.unp = reinterpret_cast<double *>(q); q += (size_t)MP * KP * 8; }
-    else w.unp = b->un + (size_t)env * MP * KP;
+    else w.unp = reinterpret_cast<double *>(er + L.e_un);
     w.jstL = reinterpret_cast<uint32_t *>(q); q += (size_t)JP * 4;
     w.dueL = reinterpret_cast<int32_t *>(q); q += (size_t)JP * 4;
     w.jinfoL = reinterpret_cast<uint32_t *>(q);
-    const size_t ko = (size_t)w.inst * KP;
+    // ---- issue every load
+    const InstHeader h = *reinterpret_cast<const InstHeader *>(ir);
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int k = c * kWave + w.lane;
-        w.kA[c] = b->kinfoA[ko + k]; w.kB[c] = b->kinfoB[ko + k];
-        w.elig[c] = b->elig[ko + k]; w.fmask[c] = b->fmask[ko + k];
-        w.rate_sum[c] = b->rate_sum[ko + k]; w.time_sum[c] = b->time_sum[ko + k];
+        w.kA[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kA)[k];
+        w.kB[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kB)[k];
+        w.elig[c] = reinterpret_cast<const uint32_t *>(ir + L.i_elig)[k];
+        w.fmask[c] = reinterpret_cast<const uint32_t *>(ir + L.i_fmask)[k];
+        w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
+        w.rate_sum[c] = reinterpret_cast<const double *>(ir + L.i_rsum)[k];
+        w.time_sum[c] = reinterpret_cast<const double *>(ir + L.i_tsum)[k];
     }
-    w.p_i = b->p + (size_t)w.inst * MP * KP;
-    w.rate_i = b->rate + (size_t)w.inst * MP * KP;
-    w.arr_i = b->arr + (size_t)w.inst * MP * KP;
-    for (int n = w.lane; n < w.njobs; n += kWave) {
-        w.dueL[n] = b->due[(size_t)w.inst * JP + n];
-        w.jinfoL[n] = b->jinfo[(size_t)w.inst * JP + n];
+    const int32_t due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
+    const uint32_t jinfo0 = reinterpret_cast<const uint32_t *>(ir + L.i_jinfo)[w.lane];
+    uint32_t jst0 = 0;
+    unsigned long long word = 0ull;
+    int tend0 = 0, mjob0 = -1;
+    if (load_state) {
+        jst0 = reinterpret_cast<const uint32_t *>(er + L.e_jst)[w.lane];
+        if (w.lane < 18) word = reinterpret_cast<const unsigned long long *>(er)[w.lane];
+        if (w.lane < MP) {
+            tend0 = reinterpret_cast<const int32_t *>(er + L.e_tend)[w.lane];
+            mjob0 = reinterpret_cast<const int32_t *>(er + L.e_mjob)[w.lane];
+        }
     }
+    w.p_i = reinterpret_cast<const uint16_t *>(ir + L.i_p);
+    w.rate_i = reinterpret_cast<const double *>(ir + L.i_rate);
+    w.arr_i = reinterpret_cast<const double *>(ir + L.i_arr);
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
-}
-
-template <int KC>
-__device__ __forceinline__ void load_dynamic(W<KC> &w, bool un_lds) {
-    const DevBatch *b = w.b;
-    const int MP = b->MP, KP = b->KP, JP = b->JP;
-    const unsigned long long *sw = reinterpret_cast<const unsigned long long *>(b->scal + w.env);
-    unsigned long long word = w.lane < 18 ? sw[w.lane] : 0ull;
+    // ---- consume
+    w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
+    w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
+    w.dueL[w.lane] = due0; w.jinfoL[w.lane] = jinfo0;
+    for (int n = kWave + w.lane; n < w.njobs; n += kWave) {
+        w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
+        w.jinfoL[n] = reinterpret_cast<const uint32_t *>(ir + L.i_jinfo)[n];
+    }
+    if (!load_state) return;
+    w.jstL[w.lane] = jst0;
+    for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + L.e_jst)[n];
     const int lo = (int)(word & 0xFFFFFFFFull), hi = (int)(word >> 32);
     w.t = rl(lo, 0); w.step_count = rl(hi, 0);
     w.done = rl(lo, 1); w.n_unassigned = rl(hi, 1);
@@ -176,17 +205,15 @@ __device__ __forceinline__ void load_dynamic(W<KC> &w, bool un_lds) {
     w.completion = rl(lo, 4); w.completion_last = rl(hi, 4);
     w.tard_done = (long long)(((unsigned long long)(uint32_t)rl(hi, 5) << 32) | (uint32_t)rl(lo, 5));
     w.delay_sum = (long long)(((unsigned long long)(uint32_t)rl(hi, 6) << 32) | (uint32_t)rl(lo, 6));
-    // obs_prev[i] sits in word 8+i; move it to lane i
-    {
+    {   // obs_prev[i] sits in word 8+i; move it to lane i
         const int src = (w.lane + 8) & 63;
         const int plo = __builtin_amdgcn_ds_bpermute(src << 2, lo), phi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
         w.obs_prev_l = __hiloint2double(phi, plo);
     }
-    w.tend_m = w.lane < w.M ? b->tend[(size_t)w.env * MP + w.lane] : 0;
-    w.mjob_m = w.lane < w.M ? b->mjob[(size_t)w.env * MP + w.lane] : -1;
-    for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = b->jst[(size_t)w.env * JP + n];
+    w.tend_m = w.lane < w.M ? tend0 : 0;
+    w.mjob_m = w.lane < w.M ? mjob0 : -1;
     if (un_lds) {
-        const double *src = b->un + (size_t)w.env * MP * KP;
+        const double *src = reinterpret_cast<const double *>(er + L.e_un);
         for (int m = 0; m < w.M; ++m)
 #pragma unroll
             for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = src[m * KP + c * kWave + w.lane];
@@ -197,7 +224,9 @@ __device__ __forceinline__ void load_dynamic(W<KC> &w, bool un_lds) {
 template <int KC>
 __device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
     const DevBatch *b = w.b;
-    const int MP = b->MP, KP = b->KP, JP = b->JP;
+    const int KP = b->KP;
+    const Layout &L = b->L;
+    unsigned char *er = w.er;
     wave_sync();
     // rebuild the 18 words lane-wise
     unsigned long long word = 0;
@@ -218,15 +247,14 @@ __device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
         const int plo = __builtin_amdgcn_ds_bpermute(src << 2, lo), phi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
         if (w.lane >= 8 && w.lane < 18) word = pk((uint32_t)plo, (uint32_t)phi);
     }
-    unsigned long long *sw = reinterpret_cast<unsigned long long *>(b->scal + w.env);
-    if (w.lane < 18) sw[w.lane] = word;
+    if (w.lane < 18) reinterpret_cast<unsigned long long *>(er)[w.lane] = word;
     if (w.lane < w.M) {
-        b->tend[(size_t)w.env * MP + w.lane] = w.tend_m;
-        b->mjob[(size_t)w.env * MP + w.lane] = w.mjob_m;
+        reinterpret_cast<int32_t *>(er + L.e_tend)[w.lane] = w.tend_m;
+        reinterpret_cast<int32_t *>(er + L.e_mjob)[w.lane] = w.mjob_m;
     }
-    for (int n = w.lane; n < w.njobs; n += kWave) b->jst[(size_t)w.env * JP + n] = w.jstL[n];
+    for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + L.e_jst)[n] = w.jstL[n];
     if (un_lds) {
-        double *dst = b->un + (size_t)w.env * MP * KP;
+        double *dst = reinterpret_cast<double *>(er + L.e_un);
         for (int m = 0; m < w.M; ++m)
 #pragma unroll
             for (int c = 0; c < KC; ++c) dst[m * KP + c * kWave + w.lane] = w.unp[m * KP + c * kWave + w.lane];
@@ -276,7 +304,7 @@ __device__ __forceinline__ void compute_params(W<KC> &w) {
         }
         w.nun[c] = idx; w.cnt_a[c] = cnt_a; w.cnt_e[c] = cnt_e; w.max_a[c] = max_a; w.max_e[c] = max_e;
         w.fifo_cnt[c] = fifo; w.head_job[c] = head; w.due_min[c] = dmin; w.tard[c] = tard;
-        w.urg[c] = sum_e / (double)idx;                                 // :153 (read only for available k, idx >= 1)
+        w.sum_e[c] = sum_e;                                             // :153 urgency = sum_e / nun, formed on demand
     }
 }
 
@@ -370,18 +398,27 @@ __device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
         anyav |= av[c]; anyfav |= fav[c];
     }
     if (!anyav) { w.status |= FJSP_ST_NO_EVENT; return -1; }
+    // kind_task_delivery_urgency (:153) = sum(estimated delays) / len(list); only rules 1, 2, 4 read it
+    double urg[KC];
+    if (a0 == 0 || a0 == 1 || a0 == 3) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) urg[c] = w.sum_e[c] / (double)w.nun[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) urg[c] = 0.0;
+    }
     switch (a0) {
     case 0: {   // rule 1 :269-273
         uint64_t de[KC]; uint64_t any = 0;
 #pragma unroll
         for (int c = 0; c < KC; ++c) { de[c] = av[c] & __ballot(w.cnt_e[c] > 0); any |= de[c]; }
-        return any ? argmax_f64<KC>(de, w.max_e) : argmax_f64<KC>(av, w.urg);
+        return any ? argmax_f64<KC>(de, w.max_e) : argmax_f64<KC>(av, urg);
     }
     case 1: {   // rule 2 :274-278
         uint64_t da[KC]; uint64_t any = 0;
 #pragma unroll
         for (int c = 0; c < KC; ++c) { da[c] = av[c] & __ballot(w.cnt_a[c] > 0); any |= da[c]; }
-        return any ? argext_i32<KC, true>(da, w.max_a) : argmax_f64<KC>(av, w.urg);
+        return any ? argext_i32<KC, true>(da, w.max_a) : argmax_f64<KC>(av, urg);
     }
     case 2: {   // rule 3 :279-283, Tasks.gap class_FJSSP.py:70-72
         double gap[KC];
@@ -390,7 +427,7 @@ __device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
         return anyfav ? argmax_f64<KC>(fav, gap) : argmax_f64<KC>(av, gap);
     }
     case 3:     // rule 4 :284-288
-        return anyfav ? argmax_f64<KC>(fav, w.urg) : argmax_f64<KC>(av, w.urg);
+        return anyfav ? argmax_f64<KC>(fav, urg) : argmax_f64<KC>(av, urg);
     case 4:     // rule 5 :289-293
         return anyfav ? argext_i32<KC, false>(fav, w.due_min) : argext_i32<KC, false>(av, w.due_min);
     case 5:     // rule 6 :294-295
@@ -429,21 +466,22 @@ __device__ __forceinline__ double machine_gap_ave(const W<KC> &w, int m) {
 // SO_FJSSP.py:300-322 machine_select.  Candidate lists are visited in CPython's
 // list(set & set) order (fjsp_pyset.h): ascending for M <= 8, not always beyond.
 template <int KC>
-__device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint32_t idle) {
+__device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel) {
     const int KP = w.b->KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const uint32_t elig_s = rlu(pick<KC>(w.elig, cs), ls), fm_s = rlu(pick<KC>(w.fmask, cs), ls);
-    const uint32_t first4 = uniu(w.b->efirst4[(size_t)w.inst * KP + k_sel]);
+    const uint32_t first4 = rlu(pick<KC>(w.first4, cs), ls);
     const CandList sel = pyset_and(idle, elig_s, first4, false);   // machine_selectable_list :302
     const CandList fsel = pyset_and(idle, fm_s, 0u, true);         // fluid_machine_selectable_list :303
     if (sel.n == 0) { w.status |= FJSP_ST_NO_EVENT; return -1; }
     // lane m: gap_rj_dict[m][k_sel] (class_FJSSP.py:137-142) and p[m][k_sel]
-    double g = 0.0;
+    double g = 0.0, un = 0.0;
     int pm = 0;
     if (w.lane < w.M && ((sel.mask >> w.lane) & 1u)) {
         const int o = w.lane * KP + k_sel;
         pm = w.p_i[o];
-        g = w.unp[o] - (w.arr_i[o] - (double)w.t * w.rate_i[o]);
+        un = w.unp[o];
+        g = un - (w.arr_i[o] - (double)w.t * w.rate_i[o]);
     }
     auto visit = [&](const CandList &l, auto &&f) {
         if (l.asc) { uint32_t m = l.mask; while (m) { f((int)__builtin_ctz(m)); m &= m - 1; } }
@@ -465,33 +503,36 @@ __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint3
         visit(l, [&](int m) { const double v = machine_gap_ave<KC>(w, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
+    int m_sel;
     switch (a1) {
-    case 0: return argmax_gap(fsel.n ? fsel : sel);       // rule 1 :304-308
-    case 1: return argmax_gap(sel);                       // rule 2 :309-310
-    case 2: return argmin_p(sel);                         // rule 3 :311-312
-    case 3: return argmax_gave(fsel.n ? fsel : sel);      // rule 4 :313-317
-    case 4: return cand_at(sel, rng_choice(w, sel.n));    // rule 5 :318-319
+    case 0: m_sel = argmax_gap(fsel.n ? fsel : sel); break;       // rule 1 :304-308
+    case 1: m_sel = argmax_gap(sel); break;                       // rule 2 :309-310
+    case 2: m_sel = argmin_p(sel); break;                         // rule 3 :311-312
+    case 3: m_sel = argmax_gave(fsel.n ? fsel : sel); break;      // rule 4 :313-317
+    case 4: m_sel = cand_at(sel, rng_choice(w, sel.n)); break;    // rule 5 :318-319
     default:
-        w.status |= FJSP_ST_BAD_MACHINE_RULE;             // MyError :321
+        w.status |= FJSP_ST_BAD_MACHINE_RULE;                     // MyError :321
         return -1;
     }
+    *p_sel = rl(pm, m_sel);
+    *un_sel = rld(un, m_sel);
+    return m_sel;
 }
 
 // SO_FJSSP.py:176-250: dispatch the FIFO head of k_sel on m_sel, then advance
 // the clock until some operation type is available again (or the episode ends).
 template <int KC>
-__device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_sel) {
+__device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_sel, int pm, double un_sel) {
     const int KP = w.b->KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
     const int Jr = (int)((rlu(pick<KC>(w.kB, cs), ls) >> 8) & 0xFFu);
-    const int pm = w.p_i[m_sel * KP + k_sel];
     const int time_end = w.t + pm;                                           // :184
     const uint32_t js = w.jstL[job];
     const int nj = (int)(js & 0xFFu) + 1;
     if (w.lane == 0) {
         w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);                        // :186-191
-        w.unp[m_sel * KP + k_sel] -= 1.0;                                    // :198
+        w.unp[m_sel * KP + k_sel] = un_sel - 1.0;                            // :198
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
@@ -537,55 +578,60 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_
 // SO_FJSSP.py:78-97 state_extract (+ the ratios of update_parameter :156-165).
 // Needs compute_params() at the current clock.  Returns tard_unproc
 // (delay_time_sum_unprocessed, :110-122) and leaves obs[0..n_obs) in LDS scratch.
+//
+// The three mean/std pairs are strictly sequential float sums (:86-95).  Their
+// operands go to LDS and every lane walks one of the arrays in order (lane 1:
+// gap_rate, every other lane: finish_rate; then all lanes: machine time_end), so
+// the chains cost one LDS read + one add per element instead of cross-lane traffic,
+// and two chains advance per instruction.
 template <int KC>
 __device__ __forceinline__ long long observe(W<KC> &w) {
     const int K = w.K, M = w.M;
-    // ---- integer statistics (order-free): DPP reductions
-    int nun_s = 0, a_s = 0, e_s = 0, ja_s = 0, je_s = 0, jn_s = 0;
+    // ---- integer statistics (order-free): packed DPP reductions (totals < 65536, checked at create)
+    uint32_t nun_s = 0, a_s = 0, e_s = 0, ja_s = 0, je_s = 0;
     long long tu = 0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const bool last = ((w.kB[c] >> 24) & 1u) != 0;
-        nun_s += w.nun[c]; a_s += w.cnt_a[c]; e_s += w.cnt_e[c];
-        if (last) { ja_s += w.cnt_a[c]; je_s += w.cnt_e[c]; jn_s += w.nun[c]; tu += w.tard[c]; }
+        nun_s += (uint32_t)w.nun[c]; a_s += (uint32_t)w.cnt_a[c]; e_s += (uint32_t)w.cnt_e[c];
+        if (last) { ja_s += (uint32_t)w.cnt_a[c]; je_s += (uint32_t)w.cnt_e[c]; tu += w.tard[c]; }
     }
-    const int task_number = wave_sum(nun_s), delay_a = wave_sum(a_s), delay_e = wave_sum(e_s);
-    const int job_a = wave_sum(ja_s), job_e = wave_sum(je_s), job_number = wave_sum(jn_s);
-    const long long tard_unproc = wave_sum_i64(tu);
-    // ---- machine completion-time spread (:84-87)
-    const int tsum = wave_sum(w.lane < M ? w.tend_m : 0);
-    const double ct_ave = (double)tsum / (double)M;
-    double s = 0.0;
-    for (int m = 0; m < M; ++m) {
-        const double d = (double)rl(w.tend_m, m) - ct_ave;
-        s = s + d * d;                                   // math.pow(d, 2)
-    }
-    const double ct_std = sqrt(s / (double)M);
-    // ---- per operation type rates (class_FJSSP.py:66-76), serial sums in r-major order (:88-95)
-    double fr[KC], gr[KC];
+    const uint32_t r1 = (uint32_t)wave_sum((int)(nun_s | (a_s << 16)));
+    const uint32_t r2 = (uint32_t)wave_sum((int)(e_s | (ja_s << 16)));
+    const uint32_t r3 = (uint32_t)wave_sum((int)(je_s | ((uint32_t)(tu >> 24) << 16)));
+    const uint32_t r4 = (uint32_t)wave_sum((int)(tu & 0xFFFFFF));
+    const int task_number = (int)(r1 & 0xFFFFu), delay_a = (int)(r1 >> 16);
+    const int delay_e = (int)(r2 & 0xFFFFu), job_a = (int)(r2 >> 16);
+    const int job_e = (int)(r3 & 0xFFFFu), job_number = w.n_unassigned;
+    const long long tard_unproc = (long long)r4 + ((long long)(r3 >> 16) << 24);
+    // ---- operands of the serial sums
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int tot = (int)(w.kA[c] >> 16);
-        fr[c] = (double)(tot - w.nun[c]) / (double)tot;                      // finish_rate
-        gr[c] = ((double)w.nun[c] - fluid_q(w, c)) / (double)tot;            // gap_rate
+        const int k = c * kWave + w.lane;
+        w.frL[k] = (double)(tot - w.nun[c]) / (double)tot;                   // finish_rate  class_FJSSP.py:74-76
+        w.grL[k] = ((double)w.nun[c] - fluid_q(w, c)) / (double)tot;         // gap_rate     class_FJSSP.py:66-68
     }
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const int cnt = min(kWave, K - c * kWave);
-        for (int i = 0; i < cnt; ++i) { s1 = s1 + rld(fr[c], i); s2 = s2 + rld(gr[c], i); }
-    }
-    const double cro_ave = s1 / (double)K, gap_ave = s2 / (double)K;
-    double v1 = 0.0, v2 = 0.0;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const int cnt = min(kWave, K - c * kWave);
-        for (int i = 0; i < cnt; ++i) {
-            const double d1 = rld(fr[c], i) - cro_ave, d2 = rld(gr[c], i) - gap_ave;
-            v1 = v1 + d1 * d1; v2 = v2 + d2 * d2;
-        }
-    }
-    const double cro_std = sqrt(v1 / (double)K), gap_std = sqrt(v2 / (double)K);
+    if (w.lane < 32) w.tdL[w.lane] = (double)w.tend_m;
+    wave_sync();
+    // ---- per operation type: mean then population std, r-major order (:88-95)
+    const double *src = w.lane == 1 ? w.grL : w.frL;
+    double s = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < K; ++i) s = s + src[i];
+    const double ave = s / (double)K;
+    double v = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < K; ++i) { const double d = src[i] - ave; v = v + d * d; }      // math.pow(d, 2)
+    const double sd = sqrt(v / (double)K);
+    // ---- machines: ct_m_ave (:384-385; an exact integer sum, so the f64 walk is exact too) and std (:86-87)
+    double sm = 0.0;
+    for (int m = 0; m < M; ++m) sm = sm + w.tdL[m];
+    const double ct_ave = sm / (double)M;
+    double vm = 0.0;
+    for (int m = 0; m < M; ++m) { const double d = w.tdL[m] - ct_ave; vm = vm + d * d; }
+    const double ct_std = sqrt(vm / (double)M);
+    const double cro_ave = rld(ave, 0), cro_std = rld(sd, 0), gap_ave = rld(ave, 1), gap_std = rld(sd, 1);
     double dro_a = 0.0, dro_e = 0.0, drj_a = 0.0, drj_e = 0.0;
     if (!w.done) {                                                           // :156-165
         dro_a = (double)delay_a / (double)task_number; dro_e = (double)delay_e / (double)task_number;
@@ -610,7 +656,7 @@ __device__ __forceinline__ void emit_state(W<KC> &w, double *state_out, bool zer
     if (w.lane < n_obs) w.obs_prev_l = cur;
     if (state_out) {
         double *o = state_out + (size_t)w.env * w.b->state_size;
-        if (w.lane < n_static) o[w.lane] = w.b->sstate[(size_t)w.inst * 8 + w.lane];
+        if (w.lane < n_static) o[w.lane] = inst_ptr<const double>(*w.b, w.inst, w.b->L.i_ss)[w.lane];
         if (w.lane < n_obs) { o[n_static + w.lane] = cur; o[n_static + n_obs + w.lane] = gap; }
     }
     wave_sync();
@@ -640,10 +686,12 @@ template <int KC>
 __device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, double *state_out, int *k_out, int *m_out) {
     const uint32_t idle = ~w.busy & w.mmask;
     const int k_sel = task_select<KC>(w, a0, idle);
-    const int m_sel = k_sel >= 0 ? machine_select<KC>(w, a1, k_sel, idle) : -1;
+    int pm = 0;
+    double un_sel = 0.0;
+    const int m_sel = k_sel >= 0 ? machine_select<KC>(w, a1, k_sel, idle, &pm, &un_sel) : -1;
     *k_out = k_sel; *m_out = m_sel;
     if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
-    dispatch_and_advance<KC>(w, k_sel, m_sel);
+    dispatch_and_advance<KC>(w, k_sel, m_sel, pm, un_sel);
     w.step_count++;                                                          // :252
     compute_params<KC>(w);
     const long long tard_unproc = observe<KC>(w);                           // :256
@@ -660,32 +708,34 @@ __device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, double *sta
 __global__ void fluid_tables_kernel(DevBatch b) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= b.n_inst * b.KP) return;
-    const int inst = idx / b.KP, k = idx % b.KP;
-    const InstHeader h = b.ihdr[inst];
-    const size_t mo = (size_t)inst * b.MP * b.KP;
+    const int inst = idx / b.KP, k = idx % b.KP, KP = b.KP;
+    const InstHeader h = *inst_ptr<const InstHeader>(b, inst, 0);
+    const uint16_t *p = inst_ptr<const uint16_t>(b, inst, b.L.i_p);
+    const double *x = inst_ptr<const double>(b, inst, b.L.i_x);
+    double *rate = inst_ptr<double>(b, inst, b.L.i_rate), *arr = inst_ptr<double>(b, inst, b.L.i_arr);
     uint32_t fm = 0;
     double s = 0.0;
-    const double q0 = (double)(b.kinfoA[(size_t)inst * b.KP + k] >> 16);
+    const double q0 = (double)(inst_ptr<const uint32_t>(b, inst, b.L.i_kA)[k] >> 16);
+    const bool valid = k < h.K;
     for (int m = 0; m < h.M; ++m) {
-        const int pm = b.p[mo + (size_t)m * b.KP + k];
+        const int pm = p[m * KP + k];
         double r = 0.0;
-        if (k < h.K && pm > 0) {
-            const double xv = b.x[mo + (size_t)m * b.KP + k];
+        if (valid && pm > 0) {
+            const double xv = x[m * KP + k];
             r = xv * (1.0 / (double)pm);                // :164, :288-289
             if (xv != 0) fm |= 1u << m;                 // :290-292
             s = s + r;                                  // :294 (ascending m)
         }
-        b.rate[mo + (size_t)m * b.KP + k] = r;
+        rate[m * KP + k] = r;
     }
-    const bool valid = k < h.K;
-    b.fmask[(size_t)inst * b.KP + k] = fm;
-    b.rate_sum[(size_t)inst * b.KP + k] = valid ? s : 0.0;
-    b.time_sum[(size_t)inst * b.KP + k] = valid ? 1.0 / s : 0.0;            // :295
+    inst_ptr<uint32_t>(b, inst, b.L.i_fmask)[k] = fm;
+    inst_ptr<double>(b, inst, b.L.i_rsum)[k] = valid ? s : 0.0;
+    inst_ptr<double>(b, inst, b.L.i_tsum)[k] = valid ? 1.0 / s : 0.0;       // :295
     for (int m = 0; m < h.M; ++m) {
-        const int pm = b.p[mo + (size_t)m * b.KP + k];
+        const int pm = p[m * KP + k];
         double a = 0.0;
-        if (valid && pm > 0) a = (q0 * b.rate[mo + (size_t)m * b.KP + k]) / s;   // :300-302
-        b.arr[mo + (size_t)m * b.KP + k] = a;
+        if (valid && pm > 0) a = (q0 * rate[m * KP + k]) / s;               // :300-302
+        arr[m * KP + k] = a;
     }
 }
 
@@ -698,29 +748,28 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
     if (env >= b.N) return;
     if (mask && mask[env] == 0) return;
     W<KC> w;
-    bind<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false);
+    open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, false);
     // rng_calls survives a reset (the reference's global `random` state does too)
-    const unsigned long long *sw = reinterpret_cast<const unsigned long long *>(b.scal + env);
-    w.rng_calls = (uint32_t)(sw[3] & 0xFFFFFFFFull);
+    w.rng_calls = env_ptr<const EnvScalars>(b, env, 0)->rng_calls;
     w.obs_prev_l = 0.0;
     init_episode<KC>(w, state_out);
     store_dynamic<KC>(w, false);
 }
 
 template <int KC>
-__global__ __launch_bounds__(256) void step_kernel(DevBatch b, const uint8_t *actions, int autoreset, double *state_out,
+__global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t *actions, int autoreset, double *state_out,
                                                    double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     const int wave = threadIdx.x >> 6;
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
     W<KC> w;
-    bind<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false);
-    load_dynamic<KC>(w, false);
+    const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
+    open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
     if (w.done) {
         if (!autoreset) {
             w.status |= FJSP_ST_STEP_AFTER_DONE;
             if (w.lane == 0) {
-                reinterpret_cast<uint32_t *>(b.scal + env)[4] = w.status;
+                env_ptr<EnvScalars>(b, env, 0)->status = w.status;
                 if (reward_out) reward_out[env] = 0.0;
                 if (done_out) done_out[env] = 1;
                 if (trace_km) { trace_km[(size_t)env * 2] = -1; trace_km[(size_t)env * 2 + 1] = -1; }
@@ -731,7 +780,6 @@ __global__ __launch_bounds__(256) void step_kernel(DevBatch b, const uint8_t *ac
     } else {
         compute_params<KC>(w);
     }
-    const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
     int k_sel, m_sel;
     const double reward = env_step<KC>(w, uni(a0), uni(a1), state_out, &k_sel, &m_sel);
     if (w.lane == 0) {
@@ -744,14 +792,13 @@ __global__ __launch_bounds__(256) void step_kernel(DevBatch b, const uint8_t *ac
 
 // T fused steps per launch: the environment lives in registers + LDS for the whole episode.
 template <int KC>
-__global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t *actions, int T, int16_t *trace_km,
+__global__ __launch_bounds__(256, 4) void rollout_kernel(DevBatch b, const uint8_t *actions, int T, int16_t *trace_km,
                                                       double *reward_out, double *state_last) {
     const int wave = threadIdx.x >> 6;
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
     W<KC> w;
-    bind<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, true), true);
-    load_dynamic<KC>(w, true);
+    open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, true), true, true);
     compute_params<KC>(w);
     for (int s = 0; s < T; ++s) {
         const size_t o = (size_t)s * b.N + env;
@@ -775,10 +822,11 @@ __global__ void read_kernel(DevBatch b, int64_t *delay, int32_t *makespan, int32
                             int32_t *step_count, uint8_t *done, uint32_t *status) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= b.N) return;
-    const EnvScalars s = b.scal[env];
-    const int M = b.ihdr[env % b.n_inst].M;
+    const EnvScalars s = *env_ptr<const EnvScalars>(b, env, 0);
+    const int M = inst_ptr<const InstHeader>(b, env % b.n_inst, 0)->M;
+    const int32_t *tend = env_ptr<const int32_t>(b, env, b.L.e_tend);
     int mx = 0;
-    for (int m = 0; m < M; ++m) mx = max(mx, b.tend[(size_t)env * b.MP + m]);   // SO_FJSSP.py:427 max time_end
+    for (int m = 0; m < M; ++m) mx = max(mx, tend[m]);                       // SO_FJSSP.py:427 max time_end
     if (delay) delay[env] = s.delay_sum;
     if (makespan) makespan[env] = mx;
     if (completion) completion[env] = s.completion;
