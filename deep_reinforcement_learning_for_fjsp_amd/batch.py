@@ -78,25 +78,27 @@ class EnvBatch(object):
             self.done.masked_fill_(mask.bool(), 0)
         return out
 
-    def step(self, actions, autoreset=False, state_out=None, reward_out=None, done_out=None):
-        """step(action): SO_FJSSP.py:168-265.  actions: uint8[N, 2] device tensor."""
+    def step(self, actions, autoreset=False, state_out=None, reward_out=None, done_out=None, mo=None):
+        """step(action): SO_FJSSP.py:168-265.  actions: uint8[N, 2] device tensor.  For the MO variant
+        actions[:, 0] is the flat action and `mo` (f64[N, 4] = w0, w1, completion, tardiness; <= 0 = None)
+        carries step()'s extra arguments (MO_FJSSP_discretes.py:88)."""
         if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         state_out = self.state if state_out is None else state_out
         reward_out = self.reward if reward_out is None else reward_out
         done_out = self.done if done_out is None else done_out
-        check(self._lib.fjsp_env_step(self._h, _ptr(actions), None, 1 if autoreset else 0, _ptr(state_out),
+        check(self._lib.fjsp_env_step(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, _ptr(state_out),
                                       _ptr(reward_out), _ptr(done_out), self._stream()))
         return state_out, reward_out, done_out
 
-    def rollout(self, actions, trace=True, rewards=True):
+    def rollout(self, actions, trace=True, rewards=True, mo=None):
         """T fused steps in one launch. actions: uint8[T, N, 2]. Returns (trace_km i16[T,N,2], reward f64[T,N], state)."""
         if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         T = actions.shape[0]
         tr = torch.full((T, self.N, 2), -1, dtype=torch.int16, device=self.device) if trace else None
         rw = torch.zeros(T, self.N, dtype=torch.float64, device=self.device) if rewards else None
-        check(self._lib.fjsp_env_rollout(self._h, _ptr(actions), int(T), _ptr(tr), _ptr(rw), _ptr(self.state),
+        check(self._lib.fjsp_env_rollout(self._h, _ptr(actions), _ptr(mo), int(T), _ptr(tr), _ptr(rw), _ptr(self.state),
                                          self._stream()))
         return tr, rw, self.state
 

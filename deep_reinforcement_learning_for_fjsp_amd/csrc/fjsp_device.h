@@ -96,10 +96,10 @@ __host__ __device__ inline T *env_ptr(const DevBatch &b, int env, uint32_t off) 
 // kernel launchers (fjsp_kernels.hip); all asynchronous on `st`, 0 = launched
 int launch_fluid_tables(const DevBatch &b, hipStream_t st);
 int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStream_t st);
-int launch_step(const DevBatch &b, const uint8_t *actions, int autoreset, double *state, double *reward, uint8_t *done,
-                int16_t *trace_km, hipStream_t st);
+int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
+                uint8_t *done, int16_t *trace_km, hipStream_t st);
 size_t rollout_lds_bytes(const DevBatch &b);
-int launch_rollout(const DevBatch &b, const uint8_t *actions, int T, int16_t *trace_km, double *reward,
+int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st);
 int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
                 int32_t *step_count, uint8_t *done, uint32_t *status, hipStream_t st);

@@ -259,23 +259,20 @@ int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *st
 int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
                   double *d_reward, uint8_t *d_done, void *stream) {
     if (!e || !d_actions) { set_error("fjsp_env_step: null argument"); return FJSP_E_ARG; }
-    if (e->b.variant != FJSP_VARIANT_SO_FJSSP) { set_error("fjsp_env_step: MO variant kernels not built yet"); return FJSP_E_UNSUPPORTED; }
-    (void)d_mo;
     DeviceGuard guard(e->device);
-    if (launch_step(e->b, d_actions, autoreset, d_state, d_reward, d_done, nullptr, (hipStream_t)stream) != 0) {
+    if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
     }
     return FJSP_OK;
 }
 
-int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, int32_t T, int16_t *d_trace_km, double *d_reward,
-                     double *d_state_last, void *stream) {
+int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t T, int16_t *d_trace_km,
+                     double *d_reward, double *d_state_last, void *stream) {
     if (!e || !d_actions || T <= 0) { set_error("fjsp_env_rollout: bad arguments"); return FJSP_E_ARG; }
-    if (e->b.variant != FJSP_VARIANT_SO_FJSSP) { set_error("fjsp_env_rollout: MO variant kernels not built yet"); return FJSP_E_UNSUPPORTED; }
     DeviceGuard guard(e->device);
     hipStream_t st = (hipStream_t)stream;
     if (rollout_lds_bytes(e->b) <= 64 * 1024) {
-        if (launch_rollout(e->b, d_actions, T, d_trace_km, d_reward, d_state_last, st) != 0) {
+        if (launch_rollout(e->b, d_actions, d_mo, T, d_trace_km, d_reward, d_state_last, st) != 0) {
             set_error("rollout_kernel launch failed"); return FJSP_E_HIP;
         }
         return FJSP_OK;
@@ -283,7 +280,7 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, int32_t T, int16_t *
     // instance too large for the LDS-resident fused kernel: T step launches on the same stream
     const size_t N = (size_t)e->b.N;
     for (int s2 = 0; s2 < T; ++s2) {
-        if (launch_step(e->b, d_actions + (size_t)s2 * N * 2, 0, d_state_last, d_reward ? d_reward + (size_t)s2 * N : nullptr,
+        if (launch_step(e->b, d_actions + (size_t)s2 * N * 2, d_mo, 2, d_state_last, d_reward ? d_reward + (size_t)s2 * N : nullptr,
                         e->d_done_scratch, d_trace_km ? d_trace_km + (size_t)s2 * N * 2 : nullptr, st) != 0) {
             set_error("step_kernel launch failed"); return FJSP_E_HIP;
         }

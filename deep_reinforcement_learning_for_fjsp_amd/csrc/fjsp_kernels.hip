@@ -39,6 +39,33 @@
 
 namespace fjsp {
 
+// ------------------------------------------------------------------ diagnostics
+// -DFJSP_STAMPS builds a DIAGNOSTIC library (never shipped, never benchmarked): lane 0 of
+// every wave adds the s_memtime delta of each phase of a step to a global table.
+#ifdef FJSP_STAMPS
+__device__ unsigned long long fjsp_stamp_acc[16];
+#define STAMP_FIELDS unsigned long long st[10]; unsigned long long st_t0;
+#define STAMP_BEGIN(w) do { for (int _i = 0; _i < 10; ++_i) (w).st[_i] = 0; (w).st_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(w, slot)                                                      \
+    do {                                                                    \
+        const unsigned long long _t1 = __builtin_amdgcn_s_memtime();        \
+        (w).st[slot] += _t1 - (w).st_t0;                                    \
+        (w).st_t0 = _t1;                                                    \
+    } while (0)
+#define STAMP_FLUSH(w)                                                                      \
+    do {                                                                                    \
+        if (__lane_id() == 0) {                                                             \
+            for (int _i = 0; _i < 10; ++_i) atomicAdd(&fjsp_stamp_acc[_i], (w).st[_i]);     \
+            atomicAdd(&fjsp_stamp_acc[15], 1ull);                                           \
+        }                                                                                   \
+    } while (0)
+#else
+#define STAMP_FIELDS
+#define STAMP_BEGIN(w)
+#define STAMP(w, slot)
+#define STAMP_FLUSH(w)
+#endif
+
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t rlu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -49,12 +76,67 @@ __device__ __forceinline__ double rld(double v, int l) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// Hand-off of LDS data between lanes of one wave.  LDS operations of a wave execute
+// in order, so only the compiler has to be kept from moving LDS accesses across the
+// point; the fence is restricted to the LDS address space so it never drains the
+// wave's outstanding global loads/stores (a plain wavefront fence costs a
+// `s_waitcnt vmcnt(0)` = one HBM round trip every time).
 __device__ __forceinline__ void wave_sync() {
-    // LDS / global traffic of one wave is issued in order; this only stops the
-    // compiler from moving memory operations across the hand-off point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// same, for data handed over through global memory (reset writing the unprocessed matrix)
+__device__ __forceinline__ void wave_sync_global() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+extern __shared__ unsigned char fjsp_lds[];
+
+// mean and population standard deviation of n operands held in LDS, accumulated
+// strictly left to right like the reference's sum() (SO_FJSSP.py:86-95):
+//     ave = (((0 + x0) + x1) + ...) / n ;  sd = sqrt((((0 + (x0-ave)^2) + ...) / n)
+// Operands are fetched 8 at a time with the next batch in flight while the current one
+// is consumed, so each chain pays the f64 add latency, not the LDS latency.  The array
+// must be readable up to the next multiple of 8 past n.  Kept out of line: it is called
+// for the per-operation chains and the machine chain, and inlining four unrolled copies
+// costs ~90 VGPRs.
+struct MeanStd { double ave, sd; };
+template <bool SQUARE>
+__device__ __forceinline__ double lds_chain(const double *src, int n, double ave) {
+    double acc = 0.0, cur[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cur[q] = src[q];
+    int i = 0;
+    for (; i + 8 < n; i += 8) {
+        double nxt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nxt[q] = src[i + 8 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (SQUARE) { const double d = cur[q] - ave; acc = acc + d * d; }      // math.pow(d, 2)
+            else acc = acc + cur[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (i + q < n) {
+            if (SQUARE) { const double d = cur[q] - ave; acc = acc + d * d; }
+            else acc = acc + cur[q];
+        }
+    }
+    return acc;
+}
+__device__ __noinline__ MeanStd lds_mean_std(uint32_t lds_byte_offset, int n) {
+    const double *src = reinterpret_cast<const double *>(fjsp_lds + lds_byte_offset);
+    MeanStd r;
+    r.ave = lds_chain<false>(src, n, 0.0) / (double)n;
+    r.sd = sqrt(lds_chain<true>(src, n, r.ave) / (double)n);
+    return r;
+}
+
 #define DPP(v, ctrl, ident) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), 0xF, 0xF, false)
 // sum over the 64 lanes; every lane must be active.  4 DPP steps give each
 // 16-lane row its total (quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
@@ -72,11 +154,6 @@ __device__ __forceinline__ int wave_min(int v) {
     v = min(v, DPP(v, 0x141, 0x7fffffff));
     v = min(v, DPP(v, 0x140, 0x7fffffff));
     return min(min(rl(v, 0), rl(v, 16)), min(rl(v, 32), rl(v, 48)));
-}
-// exact sum of non-negative 64-bit lane values below 2^47
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-    int lo = (int)(v & 0xFFFFFF), hi = (int)(v >> 24);
-    return (long long)wave_sum(lo) + ((long long)wave_sum(hi) << 24);
 }
 template <int KC, class T>
 __device__ __forceinline__ T pick(const T (&a)[KC], int c) {
@@ -126,6 +203,7 @@ struct W {
     const uint16_t *p_i;
     const double *rate_i, *arr_i;
     unsigned char *er;
+    STAMP_FIELDS
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, bool un_lds) {
@@ -504,15 +582,26 @@ __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint3
         return best;
     };
     int m_sel;
-    switch (a1) {
-    case 0: m_sel = argmax_gap(fsel.n ? fsel : sel); break;       // rule 1 :304-308
-    case 1: m_sel = argmax_gap(sel); break;                       // rule 2 :309-310
-    case 2: m_sel = argmin_p(sel); break;                         // rule 3 :311-312
-    case 3: m_sel = argmax_gave(fsel.n ? fsel : sel); break;      // rule 4 :313-317
-    case 4: m_sel = cand_at(sel, rng_choice(w, sel.n)); break;    // rule 5 :318-319
-    default:
-        w.status |= FJSP_ST_BAD_MACHINE_RULE;                     // MyError :321
-        return -1;
+    if (w.b->variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
+        switch (a1) {                                             // MO_FJSSP_discretes.py:209-230
+        case 0: m_sel = fsel.n ? argmax_gap(fsel) : argmin_p(sel); break;       // rule 1 :213-217
+        case 1: m_sel = argmax_gave(fsel.n ? fsel : sel); break;                // rule 2 :218-222
+        case 2: m_sel = argmax_gap(fsel.n ? fsel : sel); break;                 // rule 3 :223-227
+        default:
+            w.status |= FJSP_ST_BAD_MACHINE_RULE;                 // MyError :229
+            return -1;
+        }
+    } else {
+        switch (a1) {
+        case 0: m_sel = argmax_gap(fsel.n ? fsel : sel); break;       // rule 1 :304-308
+        case 1: m_sel = argmax_gap(sel); break;                       // rule 2 :309-310
+        case 2: m_sel = argmin_p(sel); break;                         // rule 3 :311-312
+        case 3: m_sel = argmax_gave(fsel.n ? fsel : sel); break;      // rule 4 :313-317
+        case 4: m_sel = cand_at(sel, rng_choice(w, sel.n)); break;    // rule 5 :318-319
+        default:
+            w.status |= FJSP_ST_BAD_MACHINE_RULE;                     // MyError :321
+            return -1;
+        }
     }
     *p_sel = rl(pm, m_sel);
     *un_sel = rld(un, m_sel);
@@ -616,21 +705,10 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
     wave_sync();
     // ---- per operation type: mean then population std, r-major order (:88-95)
     const double *src = w.lane == 1 ? w.grL : w.frL;
-    double s = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < K; ++i) s = s + src[i];
-    const double ave = s / (double)K;
-    double v = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < K; ++i) { const double d = src[i] - ave; v = v + d * d; }      // math.pow(d, 2)
-    const double sd = sqrt(v / (double)K);
+    const MeanStd ks = lds_mean_std((uint32_t)(reinterpret_cast<const unsigned char *>(src) - fjsp_lds), K);
+    const double ave = ks.ave, sd = ks.sd;
     // ---- machines: ct_m_ave (:384-385; an exact integer sum, so the f64 walk is exact too) and std (:86-87)
-    double sm = 0.0;
-    for (int m = 0; m < M; ++m) sm = sm + w.tdL[m];
-    const double ct_ave = sm / (double)M;
-    double vm = 0.0;
-    for (int m = 0; m < M; ++m) { const double d = w.tdL[m] - ct_ave; vm = vm + d * d; }
-    const double ct_std = sqrt(vm / (double)M);
+    const double ct_std = lds_mean_std((uint32_t)(reinterpret_cast<const unsigned char *>(w.tdL) - fjsp_lds), M).sd;
     const double cro_ave = rld(ave, 0), cro_std = rld(sd, 0), gap_ave = rld(ave, 1), gap_std = rld(sd, 1);
     double dro_a = 0.0, dro_e = 0.0, drj_a = 0.0, drj_e = 0.0;
     if (!w.done) {                                                           // :156-165
@@ -675,6 +753,7 @@ __device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = w.arr_i[m * KP + c * kWave + w.lane];
     wave_sync();
+    wave_sync_global();       // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
     compute_params<KC>(w);
     observe<KC>(w);                      // delay_time_sum_unprocessed is 0-relevant only after a step
     emit_state<KC>(w, state_out, true);
@@ -683,24 +762,50 @@ __device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
 // One environment step.  compute_params() must be current on entry and is
 // current again on exit (the fused kernel carries it across steps).
 template <int KC>
-__device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, double *state_out, int *k_out, int *m_out) {
+__device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, const double *mo, double *state_out, int *k_out,
+                                           int *m_out) {
+    const bool is_mo = w.b->variant == FJSP_VARIANT_MO_FJSSP_DISCRETES;
+    if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
+        if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }   // IndexError
+        a1 = a0 % 3; a0 = a0 / 3;
+    }
     const uint32_t idle = ~w.busy & w.mmask;
     const int k_sel = task_select<KC>(w, a0, idle);
+    STAMP(w, 2);
     int pm = 0;
     double un_sel = 0.0;
     const int m_sel = k_sel >= 0 ? machine_select<KC>(w, a1, k_sel, idle, &pm, &un_sel) : -1;
+    STAMP(w, 3);
     *k_out = k_sel; *m_out = m_sel;
     if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
     dispatch_and_advance<KC>(w, k_sel, m_sel, pm, un_sel);
+    STAMP(w, 4);
     w.step_count++;                                                          // :252
     compute_params<KC>(w);
+    STAMP(w, 5);
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 2
+    const long long tard_unproc = 0;            // diagnostic: no observation
+#elif defined(FJSP_ABLATE) && FJSP_ABLATE == 1
+    const long long tard_unproc = observe<KC>(w);   // diagnostic: observation computed, not emitted
+#else
     const long long tard_unproc = observe<KC>(w);                           // :256
+    STAMP(w, 6);
     emit_state<KC>(w, state_out, false);
+    STAMP(w, 7);
+#endif
     const long long delay_new = w.tard_done + tard_unproc;                   // :259
     const long long delta = delay_new - w.delay_sum;
+    const int dc = w.completion_last - w.completion;
     w.delay_sum = delay_new;                                                 // :263
     w.completion_last = w.completion;
-    return (double)(-delta);                                                 // :328 (exact integer)
+    if (!is_mo) return (double)(-delta);                                     // :328 (exact integer)
+    // MO_FJSSP_discretes.py:232-244 compute_reward(weight_vector, completion, tardiness)
+    const double w0 = mo ? mo[0] : 0.0, w1 = mo ? mo[1] : 1.0, cn = mo ? mo[2] : 0.0, tn = mo ? mo[3] : 0.0;
+    if (cn > 0.0 && tn > 0.0) return (double)dc / cn * w0 + (double)(-delta) / tn * w1;
+    if (w1 == 1.0) return (double)(-delta);
+    if (w0 == 1.0) return (double)dc;
+    w.status |= FJSP_ST_BAD_TASK_RULE;                                       // MyError :244
+    return 0.0;
 }
 
 // ------------------------------------------------------------------------ kernels
@@ -739,11 +844,9 @@ __global__ void fluid_tables_kernel(DevBatch b) {
     }
 }
 
-extern __shared__ unsigned char fjsp_lds[];
-
 template <int KC>
 __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *mask, double *state_out) {
-    const int wave = threadIdx.x >> 6;
+    const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
     if (mask && mask[env] == 0) return;
@@ -757,17 +860,27 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
 }
 
 template <int KC>
-__global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t *actions, int autoreset, double *state_out,
-                                                   double *reward_out, uint8_t *done_out, int16_t *trace_km) {
-    const int wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
+                                                      double *state_out, double *reward_out, uint8_t *done_out,
+                                                      int16_t *trace_km) {
+    const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
+#if defined(FJSP_ABLATE) && FJSP_ABLATE >= 5
+    return;                                     // diagnostic: launch overhead only
+#endif
     W<KC> w;
+    STAMP_BEGIN(w);
     const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
     open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
+    STAMP(w, 0);
+#if defined(FJSP_ABLATE) && FJSP_ABLATE >= 4
+    store_dynamic<KC>(w, false);                // diagnostic: state in / state out only
+    return;
+#endif
     if (w.done) {
-        if (!autoreset) {
-            w.status |= FJSP_ST_STEP_AFTER_DONE;
+        if (autoreset != 1) {        // 0: flag the misuse; 2: idle silently (non-fused rollout fallback)
+            if (autoreset == 0) w.status |= FJSP_ST_STEP_AFTER_DONE;
             if (w.lane == 0) {
                 env_ptr<EnvScalars>(b, env, 0)->status = w.status;
                 if (reward_out) reward_out[env] = 0.0;
@@ -780,21 +893,28 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
     } else {
         compute_params<KC>(w);
     }
+    STAMP(w, 1);
+#if defined(FJSP_ABLATE) && FJSP_ABLATE >= 3
+    store_dynamic<KC>(w, false);                // diagnostic: + compute_params
+    return;
+#endif
     int k_sel, m_sel;
-    const double reward = env_step<KC>(w, uni(a0), uni(a1), state_out, &k_sel, &m_sel);
+    const double reward = env_step<KC>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
     if (w.lane == 0) {
         if (reward_out) reward_out[env] = reward;
         if (done_out) done_out[env] = (uint8_t)w.done;
         if (trace_km) { trace_km[(size_t)env * 2] = (int16_t)k_sel; trace_km[(size_t)env * 2 + 1] = (int16_t)m_sel; }
     }
     store_dynamic<KC>(w, false);
+    STAMP(w, 8);
+    STAMP_FLUSH(w);
 }
 
 // T fused steps per launch: the environment lives in registers + LDS for the whole episode.
 template <int KC>
-__global__ __launch_bounds__(256, 4) void rollout_kernel(DevBatch b, const uint8_t *actions, int T, int16_t *trace_km,
-                                                      double *reward_out, double *state_last) {
-    const int wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T,
+                                                      int16_t *trace_km, double *reward_out, double *state_last) {
+    const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
     W<KC> w;
@@ -807,7 +927,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(DevBatch b, const uint8
         const bool live = !w.done && !(w.status & (FJSP_ST_BAD_TASK_RULE | FJSP_ST_BAD_MACHINE_RULE | FJSP_ST_NO_EVENT));
         if (live) {
             const int a0 = actions[o * 2], a1 = actions[o * 2 + 1];
-            reward = env_step<KC>(w, uni(a0), uni(a1), state_last, &k_sel, &m_sel);
+            reward = env_step<KC>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel);
         }
         if (w.lane == 0) {
             if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }
@@ -858,22 +978,22 @@ int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStrea
     DISPATCH_KC(b.KC, hipLaunchKernelGGL((reset_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, mask, state));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int launch_step(const DevBatch &b, const uint8_t *actions, int autoreset, double *state, double *reward, uint8_t *done,
-                int16_t *trace_km, hipStream_t st) {
+int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
+                uint8_t *done, int16_t *trace_km, hipStream_t st) {
     const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
-    DISPATCH_KC(b.KC, hipLaunchKernelGGL((step_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, autoreset,
+    DISPATCH_KC(b.KC, hipLaunchKernelGGL((step_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, autoreset,
                                          state, reward, done, trace_km));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 size_t rollout_lds_bytes(const DevBatch &b) { return 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, true); }
-int launch_rollout(const DevBatch &b, const uint8_t *actions, int T, int16_t *trace_km, double *reward,
+int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st) {
     const size_t lds = rollout_lds_bytes(b);
     DISPATCH_KC(b.KC, {
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<KC>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((rollout_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, T, trace_km, reward,
+        hipLaunchKernelGGL((rollout_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, T, trace_km, reward,
                            state_last);
     });
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -885,5 +1005,16 @@ int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *c
                        completion, step_time, step_count, done, status);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+#ifdef FJSP_STAMPS
+extern "C" int fjsp_debug_read_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(fjsp_stamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fjsp_stamp_acc), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace fjsp

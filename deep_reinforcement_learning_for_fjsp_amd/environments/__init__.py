@@ -1,1 +1,2 @@
 from .SO_FJSSP import SO_FJSSP_Environment, BatchedSOFJSSP  # noqa: F401
+from .MO_FJSSP_discretes import MO_FJSSP_Environment, BatchedMOFJSSP  # noqa: F401

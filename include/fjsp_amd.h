@@ -144,10 +144,11 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
                   double *d_state, double *d_reward, uint8_t *d_done, void *stream);
 
 /* T fused steps in ONE launch (rule-sweep harnesses, MO_DFJSP.py:481-518 style):
- * d_actions u8[T][N][2]; envs that finish early idle (no autoreset).
+ * d_actions u8[T][N][2]; d_mo as in fjsp_env_step (constant over the T steps);
+ * envs that finish early idle (no autoreset).
  * Trace outputs (nullable): d_trace_km i16[T][N][2] = chosen (k, m) or -1,
  * d_reward f64[T][N], d_state_last f64[N][S]. */
-int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, int32_t T, int16_t *d_trace_km,
+int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t T, int16_t *d_trace_km,
                      double *d_reward, double *d_state_last, void *stream);
 
 /* Read-back of the attributes agents / harnesses read, device

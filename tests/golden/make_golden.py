@@ -166,14 +166,16 @@ def make_solve_hook(arr, env_ref, check_lp=True):
     return hook
 
 
-def action_stream(kind, seed, n):
+def action_stream(kind, seed, n, flat=None):
     if kind[0] == "fixed":
         return np.tile(np.array(kind[1], np.uint8), (n, 1))
     rs = np.random.RandomState(seed)
+    if flat:                                   # flat action in column 0 (MO_FJSSP_discretes / SO_SFJSP)
+        return np.stack([rs.randint(0, flat, n), np.zeros(n, np.int64)], 1).astype(np.uint8)
     return np.stack([rs.randint(0, 6, n), rs.randint(0, 5, n)], 1).astype(np.uint8)
 
 
-def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, check_lp, timing=None):
+def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, check_lp, timing=None, mo=None):
     env_ref = [None]
     shim.SOLVE_HOOK = make_solve_hook(arr, env_ref, check_lp)
     env = EnvCls(use_instance=False, path=folder_parent, file_name=folder_name)
@@ -206,7 +208,10 @@ def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, ch
         while not env.done:
             a = actions[t]
             t0 = time.perf_counter()
-            s, r, d = env.step([int(a[0]), int(a[1])])
+            if mo is None:
+                s, r, d = env.step([int(a[0]), int(a[1])])
+            else:
+                s, r, d = env.step(int(a[0]), weight_vector=(mo[0], mo[1]), completion=mo[2], tardiness=mo[3])
             el += time.perf_counter() - t0
             rec["k"].append(int(koff[sel["rj"][0]]) + sel["rj"][1]); rec["m"].append(sel["m"])
             rec["job_r"].append(sel["job"][0]); rec["job_n"].append(sel["job"][1])
@@ -224,19 +229,26 @@ def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, ch
     out["makespan"] = int(out["tend"].max())
     out["delay_time_sum"] = int(env.delay_time_sum)
     out["fluid_completed_time"] = float(env.fluid_completed_time)
+    out["completion_time"] = int(getattr(env, "completion_time", 0))
     out["T"] = t
     return out, env
 
 
-def run_oracle(arr, actions, rng_seed, T):
+def run_oracle(arr, actions, rng_seed, T, mo=None):
     lp = lambda Q, now: fi.fluid_lp(arr.Jr, arr.p, Q, now)[0]
-    env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_FJSSP, rng_seed)
+    if mo is None:
+        env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_FJSSP, rng_seed)
+    else:
+        env = pyoracle.OracleEnv(arr, lp, pyoracle.MO_FJSSP_DISCRETES, rng_seed, ddt=arr.ddt)
     rec = {"k": [], "m": [], "job_r": [], "job_n": [], "reward": [], "done": [], "step_time": [], "delay": [],
            "states": []}
     state0 = env.reset()
     t = 0
     while not env.done:
-        s, r, d = env.step(actions[t])
+        if mo is None:
+            s, r, d = env.step(actions[t])
+        else:
+            s, r, d = env.step_mo(int(actions[t][0]), (mo[0], mo[1]), mo[2], mo[3])
         tr = env.trace
         rec["k"].append(tr.k_sel); rec["m"].append(tr.m_sel); rec["job_r"].append(tr.job_kind)
         rec["job_n"].append(tr.job_n); rec["reward"].append(r); rec["done"].append(d)
@@ -249,6 +261,7 @@ def run_oracle(arr, actions, rng_seed, T):
     out["makespan"] = env.makespan
     out["delay_time_sum"] = env.delay_time_sum
     out["fluid_completed_time"] = env.fluid_completed_time
+    out["completion_time"] = env.completion_time
     out["T"] = t
     return out
 
@@ -273,9 +286,11 @@ def compare(ref, ora, tag):
     assert np.array_equal(ref["tend"], ora["tend"]), tag + ": machine time_end"
     assert ref["makespan"] == ora["makespan"] and ref["delay_time_sum"] == ora["delay_time_sum"], tag
     assert ref["fluid_completed_time"] == ora["fluid_completed_time"], tag + ": fluid_completed_time"
+    if ref.get("completion_time"):
+        assert ref["completion_time"] == ora["completion_time"], tag + ": completion_time"
 
 
-def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_states):
+def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_states, mo=None):
     T = ref["T"]
     store[prefix + "inst"] = np.int32(inst_idx)
     store[prefix + "rng_seed"] = np.uint64(rng_seed)
@@ -289,6 +304,9 @@ def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_st
     store[prefix + "final"] = np.array([ref["makespan"], ref["delay_time_sum"], T], np.int64)
     store[prefix + "states_sha256"] = np.frombuffer(hashlib.sha256(bits(ref["states"]).tobytes()).digest(), np.uint8)
     store[prefix + "state_last"] = ref["states"][-1]
+    store[prefix + "completion"] = np.int64(ref.get("completion_time", 0))
+    if mo is not None:
+        store[prefix + "mo"] = np.array([mo[0], mo[1], -1.0 if mo[2] is None else mo[2], -1.0 if mo[3] is None else mo[3]], np.float64)
     if full_states:
         store[prefix + "states"] = ref["states"]
 
@@ -303,15 +321,20 @@ def store_instance(store, prefix, arr, name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default=None, help="generate only this suite (the others keep their files)")
     args = ap.parse_args()
     from environments.SO_FJSSP import SO_FJSSP_Environment
+    from environments.MO_FJSSP_discretes import MO_FJSSP_Environment
 
     tmp = tempfile.mkdtemp(prefix="fjsp_golden_")
     report = []
     ALL_PAIRS = [("fixed", (a0, a1)) for a0 in range(6) for a1 in range(5)]
 
-    def suite(name, cases, plans_store, plans_verify, full_state_eps):
-        """cases: list of (label, InstanceSet, idx, folder_parent, folder_name)."""
+    def suite(name, cases, plans_store, plans_verify, full_state_eps, variant="so"):
+        """cases: list of (label, arrays, folder_parent, folder_name)."""
+        if args.only and args.only != name:
+            return
+        EnvCls = SO_FJSSP_Environment if variant == "so" else MO_FJSSP_Environment
         store = {}
         suite_base = splitmix64(sum(ord(ch) for ch in name) * 7919)
         store["rng_seed_base"] = np.uint64(suite_base)
@@ -322,23 +345,37 @@ def main():
             store_instance(store, "i%d_" % ci, arr, label)
             Tmax = int(sum(int(arr.count[s][r]) * int(arr.Jr[r]) for s in range(arr.S) for r in range(arr.R))) + 8
             checked_loader = False
-            for (kind, seed, keep) in plans_store(ci) + [(k_, s_, False) for (k_, s_) in plans_verify(ci)]:
-                actions = action_stream(kind, seed, Tmax)
+            mo_memo = {}
+            for plan in plans_store(ci) + [tuple(pl) + (False,) for pl in plans_verify(ci)]:
+                if variant == "so":
+                    (kind, seed, keep), mo = plan, None
+                else:
+                    # (kind, seed, mo_spec, keep); mo_spec = (w0, w1, use_normalisers)
+                    kind, seed, mo_spec, keep = plan
+                    cn = mo_memo.get("completion") if mo_spec[2] else None
+                    tn = mo_memo.get("tardiness") if mo_spec[2] else None
+                    mo = (mo_spec[0], mo_spec[1], cn, tn)
+                actions = action_stream(kind, seed, Tmax, 18 if variant == "mo" else None)
                 # stored episode e of a suite plays with random.choice stream seed
                 # suite_base + e * 1000003 == the seed env e of a batch created with
                 # rng_seed = suite_base gets (fjsp_kernels.hip bind()); verify-only
                 # episodes use an unrelated seed
                 rng_seed = (suite_base + ep_id * 1000003) & MASK64 if keep else splitmix64(seed * 1000003 + ci)
-                ref, env = run_reference(SO_FJSSP_Environment, arr, parent, folder, actions, rng_seed,
-                                         check_lp=(n_eps % 16 == 0), timing=timing)
+                ref, env = run_reference(EnvCls, arr, parent, folder, actions, rng_seed,
+                                         check_lp=(n_eps % 16 == 0), timing=timing, mo=mo)
+                if variant == "mo":      # MPPPO.py:161-164: the single-objective runs supply the normalisers
+                    if mo[0] == 1 and mo[2] is None:
+                        mo_memo["completion"] = ref["completion_time"]
+                    if mo[1] == 1 and mo[2] is None:
+                        mo_memo["tardiness"] = ref["delay_time_sum"]
                 if not checked_loader:
                     check_loader_against_reference(arr, env)
                     checked_loader = True
-                ora = run_oracle(arr, actions, rng_seed, ref["T"])
+                ora = run_oracle(arr, actions, rng_seed, ref["T"], mo=mo)
                 compare(ref, ora, "%s/%s/%s/%s" % (name, label, kind, seed))
                 n_eps += 1; n_steps += ref["T"]
                 if keep:
-                    store_episode(store, "e%d_" % ep_id, ci, kind, rng_seed, actions, ref, ep_id in full_state_eps)
+                    store_episode(store, "e%d_" % ep_id, ci, kind, rng_seed, actions, ref, ep_id in full_state_eps, mo)
                     ep_id += 1
         store["n_instances"] = np.int32(len(cases))
         store["n_episodes"] = np.int32(ep_id)
@@ -386,12 +423,51 @@ def main():
           lambda ci: [] if args.quick else [(kp, 0) for kp in ALL_PAIRS[::3]] + [(("random",), 77 + ci)],
           full_state_eps=set())
 
+    # ---- suite 4: large instances (K > 64 -> multi-chunk kernels; M > 8 -> CPython set order) ------
+    big = [("benchmark/Brandimarte_Data", "Mk04"), ("benchmark/Brandimarte_Data", "Mk06"),
+           ("benchmark/Brandimarte_Data", "Mk10"), ("MPPPO", "DDT1.0_M15_R10"), ("MPPPO", "DDT0.5_M20_R5"),
+           ("DDQN", "P83")]
+    if args.quick:
+        big = big[:2]
+    s4 = fi.InstanceSet(len(big))
+    for i, (d, f) in enumerate(big):
+        s4.load_csv(i, REF + "/data/" + d, f)
+    s4.solve_fluid()
+    cases = [(d.split("/")[-1] + "/" + f, s4.arrays(i), REF + "/data/" + d, f) for i, (d, f) in enumerate(big)]
+    suite("large", cases,
+          lambda ci: [(("random",), 31 + ci, True), (("fixed", (3, 3)), 0, True), (("fixed", (0, 4)), 0, True)],
+          lambda ci: [] if args.quick else [(("fixed", (2, 0)), 0), (("fixed", (5, 1)), 0), (("random",), 131 + ci)],
+          full_state_eps=set())
+
+    # ---- suite 5: MO_FJSSP_discretes (the environment agents/MPPPO/MPPPO.py instantiates) ---------
+    s5g = fi.InstanceSet(3).generate_range(1000, fi.bench_10x5_params())
+    mo_cases = [("benchmark/Brandimarte_Data", "Mk01"), ("MPPPO", "DDT0.5_M10_R5"), ("MPPPO", "DDT1.5_M15_R5")]
+    s5 = fi.InstanceSet(len(mo_cases) + 3)
+    cases = []
+    for i, (d, f) in enumerate(mo_cases):
+        s5.load_csv(i, REF + "/data/" + d, f)
+    for i in range(3):                                  # reload through the CSV reader so DDT parses like the reference's
+        write_csv_folder(s5g.arrays(i), os.path.join(tmp, "mo", "S%d" % i))
+        s5.load_csv(len(mo_cases) + i, os.path.join(tmp, "mo"), "S%d" % i)
+    s5.solve_fluid()
+    for i, (d, f) in enumerate(mo_cases):
+        cases.append((d.split("/")[-1] + "/" + f, s5.arrays(i), REF + "/data/" + d, f))
+    for i in range(3):
+        cases.append(("seed%d" % (1000 + i), s5.arrays(len(mo_cases) + i), os.path.join(tmp, "mo"), "S%d" % i))
+    suite("mo_discretes", cases,
+          lambda ci: [(("random",), 41 + ci, (1, 0, False), True), (("random",), 51 + ci, (0, 1, False), True),
+                      (("random",), 61 + ci, (0.5, 0.5, True), True), (("random",), 71 + ci, (0.75, 0.25, True), True),
+                      (("fixed", (4, 0)), 0, (0, 1, False), True), (("fixed", (16, 0)), 0, (0.25, 0.75, True), True)],
+          lambda ci: [] if args.quick else [(("fixed", (a, 0)), 0, (0.5, 0.5, True)) for a in range(18)],
+          full_state_eps={0, 2}, variant="mo")
+
     report.append("LP checks vs HiGHS on the reference-built model: %d solves, max objective gap %.2e, max infeasibility %.2e"
                   % (LP_STATS["solves"], LP_STATS["max_obj_gap"], LP_STATS["max_infeas"]))
     print(report[-1])
-    with open(os.path.join(HERE, "GENERATION_REPORT.txt"), "w") as f:
-        f.write("make_golden.py: every episode below was played on the reference (under oracle/ref_shim)\n"
-                "and on the C oracle and compared bit-exactly (trace, rewards, f64 states).\n\n")
+    with open(os.path.join(HERE, "GENERATION_REPORT.txt"), "a" if args.only else "w") as f:
+        if not args.only:
+            f.write("make_golden.py: every episode below was played on the reference (under oracle/ref_shim)\n"
+                    "and on the C oracle and compared bit-exactly (trace, rewards, f64 states).\n\n")
         f.write("\n".join(report) + "\n")
 
 

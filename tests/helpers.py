@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUITES = ("mk01", "synth10x5", "multijob")
+SUITES = ("mk01", "synth10x5", "multijob", "large")      # SO_FJSSP
+MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
 
 # observation entries that pass through math.pow(x, 2) + sqrt in the reference
 # (SO_FJSSP.py:86-95): glibc pow differs from x*x by 1 ulp in ~0.08 % of arguments,
@@ -13,6 +14,10 @@ SUITES = ("mk01", "synth10x5", "multijob")
 POW_OBS = (1, 3, 5)
 POW_COLS = POW_OBS + tuple(10 + i for i in POW_OBS)
 EXACT_COLS = tuple(i for i in range(20) if i not in POW_COLS)
+# MO_FJSSP_discretes state = [7 static | 9 obs | 9 deltas]; pow()-derived: static N_std, J_std
+# (MO_FJSSP_discretes.py:59-63) and obs ct_std, cro_std, gap_std (:70-80)
+MO_POW_COLS = (4, 6, 7, 9, 11, 16, 18, 20)
+MO_EXACT_COLS = tuple(i for i in range(25) if i not in MO_POW_COLS)
 POW_RTOL = 1e-12   # north_star allows 1e-5; observed differences are <= a few ulp
 POW_ATOL = 1e-12   # the v(t) - v(t-1) half cancels, so an absolute floor is needed
 
@@ -40,6 +45,9 @@ def load_suite(name):
               "state0", "tend", "final", "states_sha256", "state_last")}
         if "e%d_states" % e in z.files:
             d["states"] = z["e%d_states" % e]
+        for opt in ("mo", "completion"):
+            if "e%d_%s" % (e, opt) in z.files:
+                d[opt] = z["e%d_%s" % (e, opt)]
         d["inst"] = int(d["inst"]); d["rng_seed"] = int(d["rng_seed"]); d["T"] = int(d["final"][2])
         eps.append(d)
     return insts, eps, int(z["rng_seed_base"])
@@ -63,15 +71,20 @@ def instance_set_from(arrs):
     return s
 
 
-def play_oracle(arr, x, actions, rng_seed, variant=0):
-    """Play one episode on the C oracle; returns a dict shaped like the fixtures."""
+def play_oracle(arr, x, actions, rng_seed, variant=0, mo=None):
+    """Play one episode on the C oracle; returns a dict shaped like the fixtures.
+    mo = (w0, w1, completion, tardiness) with <= 0 standing for None selects the MO variant's step."""
     from oracle import pyoracle
-    env = pyoracle.OracleEnv(arr, x, variant, rng_seed)
+    env = pyoracle.OracleEnv(arr, x, variant, rng_seed, ddt=getattr(arr, "ddt", None) if variant else None)
     rec = {k: [] for k in ("k", "m", "job_r", "job_n", "reward", "done", "step_time", "delay", "states")}
     state0 = env.reset()
     t = 0
     while not env.done:
-        s, r, d = env.step(actions[t])
+        if mo is None:
+            s, r, d = env.step(actions[t])
+        else:
+            s, r, d = env.step_mo(int(actions[t][0]), (mo[0], mo[1]), mo[2] if mo[2] > 0 else None,
+                                  mo[3] if mo[3] > 0 else None)
         tr = env.trace
         rec["k"].append(tr.k_sel); rec["m"].append(tr.m_sel); rec["job_r"].append(tr.job_kind)
         rec["job_n"].append(tr.job_n); rec["reward"].append(r); rec["done"].append(d)
@@ -79,17 +92,17 @@ def play_oracle(arr, x, actions, rng_seed, variant=0):
         t += 1
     out = {k: np.array(v) for k, v in rec.items()}
     out.update(state0=state0, tend=env.machine_time_end(), makespan=env.makespan, delay_time_sum=env.delay_time_sum,
-               T=t, fluid_completed_time=env.fluid_completed_time)
+               T=t, fluid_completed_time=env.fluid_completed_time, completion_time=env.completion_time)
     return out
 
 
-def assert_state_close(got, want, what=""):
+def assert_state_close(got, want, what="", mo=False):
     """Kernel state vs oracle/reference state: bit-exact except the pow()-derived entries."""
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
-    ex = list(EXACT_COLS)
+    ex = list(MO_EXACT_COLS if mo else EXACT_COLS)
     if not np.array_equal(bits(got[..., ex]), bits(want[..., ex])):
         bad = np.argwhere(bits(got[..., ex]) != bits(want[..., ex]))[0]
         raise AssertionError("%s exact state entry differs at %s: got %r want %r"
                              % (what, bad, got[..., ex][tuple(bad)], want[..., ex][tuple(bad)]))
-    pw = list(POW_COLS)
+    pw = list(MO_POW_COLS if mo else POW_COLS)
     np.testing.assert_allclose(got[..., pw], want[..., pw], rtol=POW_RTOL, atol=POW_ATOL, err_msg=what)

@@ -118,6 +118,55 @@ def test_rollout_kernel_matches_reference_fixtures(torch_gpu, suite):
         assert int(final["status"][e]) == 0 and int(final["done"][e]) == 1 and int(final["step_count"][e]) == Te
 
 
+def test_mo_discretes_matches_reference_fixtures(torch_gpu):
+    """MO_FJSSP_discretes (what MPPPO instantiates): per-step and fused kernels vs the reference traces,
+    with the reference's weight vectors / normalisers (MO_FJSSP_discretes.py:88,232-244)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, VARIANT_MO_FJSSP_DISCRETES
+    insts, eps, base = H.load_suite("mo_discretes")
+    s = H.instance_set_from([insts[ep["inst"]] for ep in eps])
+    T = max(ep["T"] for ep in eps)
+    actions = np.zeros((T, len(eps), 2), np.uint8)
+    for e, ep in enumerate(eps):
+        actions[:ep["T"], e] = ep["actions"]
+    actions = torch.from_numpy(actions).cuda()
+    mo = torch.from_numpy(np.stack([ep["mo"] for ep in eps])).cuda()
+    for mode in ("step", "rollout"):
+        b = EnvBatch(s, len(eps), variant=VARIANT_MO_FJSSP_DISCRETES, rng_seed=base)
+        assert b.state_size == 25
+        st0 = b.reset().cpu().numpy()
+        for e, ep in enumerate(eps):
+            H.assert_state_close(st0[e], ep["state0"], "mo ep %d reset" % e, mo=True)
+        if mode == "step":
+            rewards = np.zeros((T, len(eps))); states = np.zeros((T, len(eps), 25))
+            for t in range(T):
+                st, r, d = b.step(actions[t], mo=mo)
+                rewards[t] = r.cpu().numpy(); states[t] = st.cpu().numpy()
+            trace = None
+        else:
+            trace, rw, st = b.rollout(actions, mo=mo)
+            trace = trace.cpu().numpy(); rewards = rw.cpu().numpy(); last = st.cpu().numpy()
+        fin = {k: v.cpu().numpy() for k, v in b.read().items()}
+        tend = b.machine_time_end().cpu().numpy()
+        for e, ep in enumerate(eps):
+            Te = ep["T"]
+            tag = "mo_discretes %s episode %d (%s)" % (mode, e, insts[ep["inst"]].name)
+            # weighted rewards go through f64 divisions in the same order -> bit-exact too
+            assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(ep["reward"])), tag + " reward"
+            if trace is not None:
+                assert np.array_equal(trace[:Te, e, 0], ep["k"]) and np.array_equal(trace[:Te, e, 1], ep["m"]), tag
+                H.assert_state_close(last[e], ep["state_last"], tag, mo=True)
+            else:
+                H.assert_state_close(states[Te - 1, e], ep["state_last"], tag, mo=True)
+                if "states" in ep:
+                    H.assert_state_close(states[:Te, e], ep["states"], tag, mo=True)
+            M = insts[ep["inst"]].M
+            assert np.array_equal(tend[e, :M], ep["tend"]), tag
+            assert fin["makespan"][e] == ep["final"][0] and fin["delay_time_sum"][e] == ep["final"][1], tag
+            assert fin["completion_time"][e] == int(ep["completion"]) and fin["step_count"][e] == Te, tag
+            assert fin["status"][e] & ~4 == 0, tag
+
+
 def test_full_size_batch_against_oracle_and_invariants(torch_gpu):
     """BASELINE config 2 at full size: 4096 generated 10x5 instances (seeds 1000+i), random policy.
 
@@ -213,3 +262,17 @@ def test_error_behaviour(torch_gpu):
     env2 = pickle.loads(pickle.dumps(env))
     s1 = env2.reset()
     assert np.array_equal(H.bits(s1), H.bits(s0))
+    # the MO mirror: same protocol with step()'s extra arguments
+    from deep_reinforcement_learning_for_fjsp_amd.environments import MO_FJSSP_Environment
+    mo = MO_FJSSP_Environment(use_instance=True, DDT=1.0, M=6, S=1, seed=11)
+    st = mo.reset()
+    assert st.shape == (25,) and st[1] == 6.0
+    with pytest.raises(IndexError):
+        mo.step(18, weight_vector=(0, 1))
+    with pytest.raises(MyError):
+        mo.step(3, weight_vector=(0.5, 0.5))
+    tot = 0
+    while not mo.done:
+        st, r, d = mo.step(3, weight_vector=(1, 0))
+        tot += r
+    assert -tot == mo.completion_time == max(v.time_end for v in mo.machine_dict.values())

@@ -10,13 +10,17 @@ import pytest
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("suite", H.SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES)
 def test_oracle_matches_reference_fixtures(built, suite):
     insts, eps, _ = H.load_suite(suite)
     assert eps, "empty fixture"
     for e, ep in enumerate(eps):
         a = insts[ep["inst"]]
-        got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"])
+        if suite in H.MO_SUITES:
+            got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=2, mo=ep["mo"])
+            assert got["completion_time"] == int(ep["completion"])
+        else:
+            got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"])
         tag = "%s episode %d (%s)" % (suite, e, a.name)
         assert got["T"] == ep["T"], tag
         for key in ("k", "m", "job_r", "job_n", "done", "step_time", "delay"):
@@ -39,6 +43,22 @@ def test_known_reference_values(built):
     assert ep["T"] == 55                       # one step per operation
     assert -int(ep["reward"].sum()) == int(ep["final"][1])   # rewards telescope to -delay_time_sum
     assert int(ep["final"][0]) == int(ep["tend"].max())
+
+
+def test_mo_rewards_follow_the_weighting(built):
+    """MO_FJSSP_discretes.py:232-244: single-objective weights give integer objective deltas that telescope."""
+    _, eps, _ = H.load_suite("mo_discretes")
+    seen = set()
+    for ep in eps:
+        w0, w1, cn, tn = ep["mo"]
+        if cn <= 0 and w1 == 1:
+            assert -int(ep["reward"].sum()) == int(ep["final"][1]); seen.add("tardiness")
+        if cn <= 0 and w0 == 1:
+            assert -int(ep["reward"].sum()) == int(ep["completion"]); seen.add("completion")
+        if cn > 0:
+            want = -(int(ep["completion"]) / cn * w0 + int(ep["final"][1]) / tn * w1)
+            assert abs(ep["reward"].sum() - want) < 1e-9 * max(1.0, abs(want)); seen.add("weighted")
+    assert seen == {"tardiness", "completion", "weighted"}
 
 
 def test_reward_telescopes_everywhere(built):
