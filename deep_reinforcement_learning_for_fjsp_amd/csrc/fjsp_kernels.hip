@@ -93,48 +93,28 @@ __device__ __forceinline__ void wave_sync_global() {
 }
 extern __shared__ unsigned char fjsp_lds[];
 
-// mean and population standard deviation of n operands held in LDS, accumulated
-// strictly left to right like the reference's sum() (SO_FJSSP.py:86-95):
-//     ave = (((0 + x0) + x1) + ...) / n ;  sd = sqrt((((0 + (x0-ave)^2) + ...) / n)
-// Operands are fetched 8 at a time with the next batch in flight while the current one
-// is consumed, so each chain pays the f64 add latency, not the LDS latency.  The array
-// must be readable up to the next multiple of 8 past n.  Kept out of line: it is called
-// for the per-operation chains and the machine chain, and inlining four unrolled copies
-// costs ~90 VGPRs.
-struct MeanStd { double ave, sd; };
-template <bool SQUARE>
-__device__ __forceinline__ double lds_chain(const double *src, int n, double ave) {
+// Strictly sequential float sum of n8 (a multiple of 8) operands held in LDS, left to right like
+// the reference's sum() (SO_FJSSP.py:86-95): (((0 + x0) + x1) + ...).  Operands are fetched 8 at a
+// time with the next batch in flight while the current one is consumed, so the chain pays the f64
+// add latency, not the LDS latency.  Entries past the real length hold +0.0, which is an exact
+// identity here (the running sum starts at +0.0 and can never become -0.0).
+__device__ __forceinline__ double lds_chain_sum(uint32_t lds_byte_offset, int n8) {
+    const double *src = reinterpret_cast<const double *>(fjsp_lds + lds_byte_offset);
     double acc = 0.0, cur[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) cur[q] = src[q];
-    int i = 0;
-    for (; i + 8 < n; i += 8) {
+    for (int i = 8; i < n8; i += 8) {
         double nxt[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) nxt[q] = src[i + 8 + q];
+        for (int q = 0; q < 8; ++q) nxt[q] = src[i + q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (SQUARE) { const double d = cur[q] - ave; acc = acc + d * d; }      // math.pow(d, 2)
-            else acc = acc + cur[q];
-        }
+        for (int q = 0; q < 8; ++q) acc = acc + cur[q];
 #pragma unroll
         for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if (i + q < n) {
-            if (SQUARE) { const double d = cur[q] - ave; acc = acc + d * d; }
-            else acc = acc + cur[q];
-        }
-    }
+    for (int q = 0; q < 8; ++q) acc = acc + cur[q];
     return acc;
-}
-__device__ __noinline__ MeanStd lds_mean_std(uint32_t lds_byte_offset, int n) {
-    const double *src = reinterpret_cast<const double *>(fjsp_lds + lds_byte_offset);
-    MeanStd r;
-    r.ave = lds_chain<false>(src, n, 0.0) / (double)n;
-    r.sd = sqrt(lds_chain<true>(src, n, r.ave) / (double)n);
-    return r;
 }
 
 #define DPP(v, ctrl, ident) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), 0xF, 0xF, false)
@@ -173,7 +153,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 // ------------------------------------------------------------------ wave state
 template <int KC>
 struct W {
-    const DevBatch *b;
+    // batch constants copied out of the kernel argument (keeping a pointer to the argument struct
+    // makes the compiler spill it to scratch and re-load fields through memory)
+    int KP, JP, variant, n_obs, n_static, state_size;
+    uint32_t e_jst, e_tend, e_mjob, e_un;
+    const double *sstate;
     int env, inst, lane;
     // uniform instance dims
     int K, M, njobs;
@@ -197,7 +181,7 @@ struct W {
     int32_t *dueL;
     uint32_t *jinfoL;
     double *scrL;   // 16 doubles: the observation being assembled
-    double *frL, *grL, *tdL;   // serial-sum operands: finish_rate[KP], gap_rate[KP], time_end[32]
+    double *frL, *grL, *tdL;   // serial-sum operands: finish_rate[KP], gap_rate[KP], time_end[KP] (zero padded)
     double *unp;    // unprocessed_rj matrix [MP][KP]: LDS slice (rollout) or the env record's rows (step)
     // rows of this instance / env record
     const uint16_t *p_i;
@@ -207,7 +191,7 @@ struct W {
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, bool un_lds) {
-    return (size_t)(16 + 2 * KP + 32) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 12;
+    return (size_t)(16 + 3 * KP) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 12;
 }
 
 // Bind the wave to its records and bring the environment in.  All loads below are
@@ -216,7 +200,9 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, boo
 template <int KC>
 __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
                                          bool load_state) {
-    w.b = b;
+    w.KP = b->KP; w.JP = b->JP; w.variant = b->variant; w.n_obs = b->n_obs; w.n_static = b->n_static;
+    w.state_size = b->state_size;
+    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = env % b->n_inst;
@@ -225,10 +211,10 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
     const unsigned char *ir = b->inst + (size_t)w.inst * L.i_stride;
     unsigned char *er = b->envs + (size_t)env * L.e_stride;
     w.er = er;
-    // LDS carve: [obs 16][fr KP][gr KP][td 32][un (optional)][jst][due][jinfo]
+    // LDS carve: [obs 16][fr KP][gr KP][td KP][un (optional)][jst][due][jinfo]
     w.scrL = reinterpret_cast<double *>(lds);
     w.frL = w.scrL + 16; w.grL = w.frL + KP; w.tdL = w.grL + KP;
-    unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + 32);
+    unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + KP);
     if (un_lds) { w.unp = reinterpret_cast<double *>(q); q += (size_t)MP * KP * 8; }
     else w.unp = reinterpret_cast<double *>(er + L.e_un);
     w.jstL = reinterpret_cast<uint32_t *>(q); q += (size_t)JP * 4;
@@ -264,6 +250,7 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
     w.rate_i = reinterpret_cast<const double *>(ir + L.i_rate);
     w.arr_i = reinterpret_cast<const double *>(ir + L.i_arr);
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
+    w.sstate = reinterpret_cast<const double *>(ir + L.i_ss);
     // ---- consume
     w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
     w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
@@ -301,9 +288,7 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
 
 template <int KC>
 __device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
-    const DevBatch *b = w.b;
-    const int KP = b->KP;
-    const Layout &L = b->L;
+    const int KP = w.KP;
     unsigned char *er = w.er;
     wave_sync();
     // rebuild the 18 words lane-wise
@@ -327,12 +312,12 @@ __device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
     }
     if (w.lane < 18) reinterpret_cast<unsigned long long *>(er)[w.lane] = word;
     if (w.lane < w.M) {
-        reinterpret_cast<int32_t *>(er + L.e_tend)[w.lane] = w.tend_m;
-        reinterpret_cast<int32_t *>(er + L.e_mjob)[w.lane] = w.mjob_m;
+        reinterpret_cast<int32_t *>(er + w.e_tend)[w.lane] = w.tend_m;
+        reinterpret_cast<int32_t *>(er + w.e_mjob)[w.lane] = w.mjob_m;
     }
-    for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + L.e_jst)[n] = w.jstL[n];
+    for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + w.e_jst)[n] = w.jstL[n];
     if (un_lds) {
-        double *dst = reinterpret_cast<double *>(er + L.e_un);
+        double *dst = reinterpret_cast<double *>(er + w.e_un);
         for (int m = 0; m < w.M; ++m)
 #pragma unroll
             for (int c = 0; c < KC; ++c) dst[m * KP + c * kWave + w.lane] = w.unp[m * KP + c * kWave + w.lane];
@@ -520,7 +505,7 @@ __device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
 // kind_task_tuple order of unprocessed - fluid_unprocessed, divided by (n + 1e-18).
 template <int KC>
 __device__ __forceinline__ double machine_gap_ave(const W<KC> &w, int m) {
-    const int KP = w.b->KP;
+    const int KP = w.KP;
     const double dt = (double)w.t;
     double s = 0.0;
     int n = 0;
@@ -545,7 +530,7 @@ __device__ __forceinline__ double machine_gap_ave(const W<KC> &w, int m) {
 // list(set & set) order (fjsp_pyset.h): ascending for M <= 8, not always beyond.
 template <int KC>
 __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel) {
-    const int KP = w.b->KP;
+    const int KP = w.KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const uint32_t elig_s = rlu(pick<KC>(w.elig, cs), ls), fm_s = rlu(pick<KC>(w.fmask, cs), ls);
     const uint32_t first4 = rlu(pick<KC>(w.first4, cs), ls);
@@ -582,7 +567,7 @@ __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint3
         return best;
     };
     int m_sel;
-    if (w.b->variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
+    if (w.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
         switch (a1) {                                             // MO_FJSSP_discretes.py:209-230
         case 0: m_sel = fsel.n ? argmax_gap(fsel) : argmin_p(sel); break;       // rule 1 :213-217
         case 1: m_sel = argmax_gave(fsel.n ? fsel : sel); break;                // rule 2 :218-222
@@ -612,7 +597,7 @@ __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint3
 // the clock until some operation type is available again (or the episode ends).
 template <int KC>
 __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_sel, int pm, double un_sel) {
-    const int KP = w.b->KP;
+    const int KP = w.KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
     const int Jr = (int)((rlu(pick<KC>(w.kB, cs), ls) >> 8) & 0xFFu);
@@ -693,23 +678,41 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
     const int delay_e = (int)(r2 & 0xFFFFu), job_a = (int)(r2 >> 16);
     const int job_e = (int)(r3 & 0xFFFFu), job_number = w.n_unassigned;
     const long long tard_unproc = (long long)r4 + ((long long)(r3 >> 16) << 24);
-    // ---- operands of the serial sums
+    // ---- the three mean / population-std pairs (:84-95).  Lane 0 walks finish_rate, lane 1 gap_rate,
+    // lane 2 the machines' time_end (an exact integer sum, so the f64 walk equals sum(int)/M, :384-385);
+    // the squared deviations are formed lane-parallel between the two walks so the second walk is a
+    // pure add chain as well.  Rows are zero padded to a multiple of 8 (+0.0 is an exact identity).
+    const int n8 = (K + 7) & ~7;
+    // (offset arithmetic, not a select between the pointer fields of `w`: that would pin `w` in scratch)
+    const uint32_t src_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.frL) - fjsp_lds) +
+                             (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));
+    const double len = w.lane == 2 ? (double)M : (double)K;
+    double frv[KC], grv[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int tot = (int)(w.kA[c] >> 16);
         const int k = c * kWave + w.lane;
-        w.frL[k] = (double)(tot - w.nun[c]) / (double)tot;                   // finish_rate  class_FJSSP.py:74-76
-        w.grL[k] = ((double)w.nun[c] - fluid_q(w, c)) / (double)tot;         // gap_rate     class_FJSSP.py:66-68
+        const bool valid = k < K;
+        frv[c] = valid ? (double)(tot - w.nun[c]) / (double)tot : 0.0;              // finish_rate class_FJSSP.py:74-76
+        grv[c] = valid ? ((double)w.nun[c] - fluid_q(w, c)) / (double)tot : 0.0;    // gap_rate    class_FJSSP.py:66-68
+        w.frL[k] = frv[c]; w.grL[k] = grv[c];
+        w.tdL[k] = (c == 0 && w.lane < M) ? (double)w.tend_m : 0.0;
     }
-    if (w.lane < 32) w.tdL[w.lane] = (double)w.tend_m;
     wave_sync();
-    // ---- per operation type: mean then population std, r-major order (:88-95)
-    const double *src = w.lane == 1 ? w.grL : w.frL;
-    const MeanStd ks = lds_mean_std((uint32_t)(reinterpret_cast<const unsigned char *>(src) - fjsp_lds), K);
-    const double ave = ks.ave, sd = ks.sd;
-    // ---- machines: ct_m_ave (:384-385; an exact integer sum, so the f64 walk is exact too) and std (:86-87)
-    const double ct_std = lds_mean_std((uint32_t)(reinterpret_cast<const unsigned char *>(w.tdL) - fjsp_lds), M).sd;
-    const double cro_ave = rld(ave, 0), cro_std = rld(sd, 0), gap_ave = rld(ave, 1), gap_std = rld(sd, 1);
+    const double ave = lds_chain_sum(src_off, n8) / len;
+    const double ave_fr = rld(ave, 0), ave_gr = rld(ave, 1), ave_td = rld(ave, 2);
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int k = c * kWave + w.lane;
+        const bool valid = k < K;
+        const double d1 = frv[c] - ave_fr, d2 = grv[c] - ave_gr;                    // math.pow(d, 2)
+        w.frL[k] = valid ? d1 * d1 : 0.0; w.grL[k] = valid ? d2 * d2 : 0.0;
+        if (c == 0) { const double d3 = (double)w.tend_m - ave_td; w.tdL[k] = w.lane < M ? d3 * d3 : 0.0; }
+    }
+    wave_sync();
+    const double sd = sqrt(lds_chain_sum(src_off, n8) / len);
+    const double cro_ave = ave_fr, cro_std = rld(sd, 0), gap_ave = ave_gr, gap_std = rld(sd, 1), ct_std = rld(sd, 2);
     double dro_a = 0.0, dro_e = 0.0, drj_a = 0.0, drj_e = 0.0;
     if (!w.done) {                                                           // :156-165
         dro_a = (double)delay_a / (double)task_number; dro_e = (double)delay_e / (double)task_number;
@@ -717,7 +720,7 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
     }
     if (w.lane == 0) {
         int i = 0;
-        if (w.b->variant == FJSP_VARIANT_SO_FJSSP) w.scrL[i++] = (double)M;
+        if (w.variant == FJSP_VARIANT_SO_FJSSP) w.scrL[i++] = (double)M;
         w.scrL[i++] = ct_std; w.scrL[i++] = cro_ave; w.scrL[i++] = cro_std; w.scrL[i++] = gap_ave;
         w.scrL[i++] = gap_std; w.scrL[i++] = dro_a; w.scrL[i++] = dro_e; w.scrL[i++] = drj_a; w.scrL[i++] = drj_e;
     }
@@ -728,13 +731,13 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
 // state = [static, v(t), v(t) - v(t-1)]  (SO_FJSSP.py:71-72,257-258); updates obs_prev.
 template <int KC>
 __device__ __forceinline__ void emit_state(W<KC> &w, double *state_out, bool zero_gap) {
-    const int n_obs = w.b->n_obs, n_static = w.b->n_static;
+    const int n_obs = w.n_obs, n_static = w.n_static;
     const double cur = w.lane < n_obs ? w.scrL[w.lane] : 0.0;
     const double gap = zero_gap ? cur - cur : cur - w.obs_prev_l;
     if (w.lane < n_obs) w.obs_prev_l = cur;
     if (state_out) {
-        double *o = state_out + (size_t)w.env * w.b->state_size;
-        if (w.lane < n_static) o[w.lane] = inst_ptr<const double>(*w.b, w.inst, w.b->L.i_ss)[w.lane];
+        double *o = state_out + (size_t)w.env * w.state_size;
+        if (w.lane < n_static) o[w.lane] = w.sstate[w.lane];
         if (w.lane < n_obs) { o[n_static + w.lane] = cur; o[n_static + n_obs + w.lane] = gap; }
     }
     wave_sync();
@@ -743,7 +746,7 @@ __device__ __forceinline__ void emit_state(W<KC> &w, double *state_out, bool zer
 // SO_FJSSP.py:51-76 reset (fresh-object semantics; class_FJSSP.py:173-244 for one order).
 template <int KC>
 __device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
-    const int KP = w.b->KP;
+    const int KP = w.KP;
     w.t = 0; w.step_count = 0; w.done = 0; w.n_unassigned = w.njobs; w.status = 0;
     w.seq_ctr = (uint32_t)w.njobs; w.busy = 0; w.completion = 0; w.completion_last = 0;
     w.tard_done = 0; w.delay_sum = 0;
@@ -764,7 +767,7 @@ __device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
 template <int KC>
 __device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, const double *mo, double *state_out, int *k_out,
                                            int *m_out) {
-    const bool is_mo = w.b->variant == FJSP_VARIANT_MO_FJSSP_DISCRETES;
+    const bool is_mo = w.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES;
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
         if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }   // IndexError
         a1 = a0 % 3; a0 = a0 / 3;
