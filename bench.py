@@ -59,9 +59,17 @@ def main():
                          % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the environment kernels")
+    # FJSP_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks then share devices); the driver's runs use the default: nccl == RCCL, one GPU per rank
+    backend = os.environ.get("FJSP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from deep_reinforcement_learning_for_fjsp_amd import instances as fi
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
@@ -100,7 +108,7 @@ def main():
     status = env.read()["status"]
     assert int((status != 0).sum().item()) == 0, "an environment reported an error status during the bench"
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -160,7 +168,16 @@ def main():
 
     if rank == 0:
         total_steps = N * world * args.steps
-        achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
+        # average launch duration = HIP events bracketing the K timed launches on the launch stream / K
+        # (agrees with rocprofv3's per-kernel average within ~1 %, profiles/README.md; events around every
+        # single launch read ~2 us high, reported as launch_us_per_launch_events)
+        region_us = region_ms * 1e3 / args.steps
+        achieved = bytes_per_launch / (region_us * 1e-6) / 1e9
+        traffic, traffic_note = None, None
+        tpath = os.path.join(REPO, "profiles", "traffic_step_kernel.json")
+        if os.path.exists(tpath) and N == 4096:
+            tj = json.load(open(tpath))
+            traffic, traffic_note = tj["traffic_bytes_per_launch"], tj["note"]
         out = {
             "metric": "env-steps/sec (batched SO_FJSSP 10x5)",
             "value": total_steps / elapsed,
@@ -180,10 +197,10 @@ def main():
                        "envs_per_gpu": N, "mean_ops_per_instance": float(K.mean()), "sharding": "env id range per rank, no collective",
                        "host_prep_s": round(t_prep, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "step_kernel<1>", "bytes_per_env_step": env.step_bytes,
-                         "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": kern_us,
-                         "region_us_per_launch": region_ms * 1e3 / args.steps},
+                         "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": region_us,
+                         "launch_us_per_launch_events": kern_us},
             "cpu_baseline": cpu,
             "fused": fused,
         }
