@@ -179,7 +179,6 @@ struct W {
     // wave-private LDS
     uint32_t *jstL;
     int32_t *dueL;
-    uint32_t *jinfoL;
     double *scrL;   // 16 doubles: the observation being assembled
     double *frL, *grL, *tdL;   // serial-sum operands: finish_rate[KP], gap_rate[KP], time_end[KP] (zero padded)
     double *unp;    // unprocessed_rj matrix [MP][KP]: LDS slice (rollout) or the env record's rows (step)
@@ -191,7 +190,7 @@ struct W {
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, bool un_lds) {
-    return (size_t)(16 + 3 * KP) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 12;
+    return (size_t)(16 + 3 * KP) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 8;
 }
 
 // Bind the wave to its records and bring the environment in.  All loads below are
@@ -211,15 +210,14 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
     const unsigned char *ir = b->inst + (size_t)w.inst * L.i_stride;
     unsigned char *er = b->envs + (size_t)env * L.e_stride;
     w.er = er;
-    // LDS carve: [obs 16][fr KP][gr KP][td KP][un (optional)][jst][due][jinfo]
+    // LDS carve: [obs 16][fr KP][gr KP][td KP][un (optional)][jst][due]
     w.scrL = reinterpret_cast<double *>(lds);
     w.frL = w.scrL + 16; w.grL = w.frL + KP; w.tdL = w.grL + KP;
     unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + KP);
     if (un_lds) { w.unp = reinterpret_cast<double *>(q); q += (size_t)MP * KP * 8; }
     else w.unp = reinterpret_cast<double *>(er + L.e_un);
     w.jstL = reinterpret_cast<uint32_t *>(q); q += (size_t)JP * 4;
-    w.dueL = reinterpret_cast<int32_t *>(q); q += (size_t)JP * 4;
-    w.jinfoL = reinterpret_cast<uint32_t *>(q);
+    w.dueL = reinterpret_cast<int32_t *>(q);
     // ---- issue every load
     const InstHeader h = *reinterpret_cast<const InstHeader *>(ir);
 #pragma unroll
@@ -234,13 +232,18 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
         w.time_sum[c] = reinterpret_cast<const double *>(ir + L.i_tsum)[k];
     }
     const int32_t due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
-    const uint32_t jinfo0 = reinterpret_cast<const uint32_t *>(ir + L.i_jinfo)[w.lane];
     uint32_t jst0 = 0;
-    unsigned long long word = 0ull;
     int tend0 = 0, mjob0 = -1;
+    double obs0 = 0.0;
+    EnvScalars sc;      // uniform address: the compiler fetches it with scalar loads, no cross-lane traffic
     if (load_state) {
         jst0 = reinterpret_cast<const uint32_t *>(er + L.e_jst)[w.lane];
-        if (w.lane < 18) word = reinterpret_cast<const unsigned long long *>(er)[w.lane];
+        const EnvScalars *es = reinterpret_cast<const EnvScalars *>(er);
+        sc.t = es->t; sc.step_count = es->step_count; sc.done = es->done; sc.n_unassigned = es->n_unassigned;
+        sc.status = es->status; sc.seq_ctr = es->seq_ctr; sc.rng_calls = es->rng_calls; sc.busy = es->busy;
+        sc.completion = es->completion; sc.completion_last = es->completion_last;
+        sc.tard_done = es->tard_done; sc.delay_sum = es->delay_sum;
+        if (w.lane < 10) obs0 = es->obs_prev[w.lane];
         if (w.lane < MP) {
             tend0 = reinterpret_cast<const int32_t *>(er + L.e_tend)[w.lane];
             mjob0 = reinterpret_cast<const int32_t *>(er + L.e_mjob)[w.lane];
@@ -254,27 +257,16 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
     // ---- consume
     w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
     w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
-    w.dueL[w.lane] = due0; w.jinfoL[w.lane] = jinfo0;
-    for (int n = kWave + w.lane; n < w.njobs; n += kWave) {
-        w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
-        w.jinfoL[n] = reinterpret_cast<const uint32_t *>(ir + L.i_jinfo)[n];
-    }
+    w.dueL[w.lane] = due0;
+    for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
     if (!load_state) return;
     w.jstL[w.lane] = jst0;
     for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + L.e_jst)[n];
-    const int lo = (int)(word & 0xFFFFFFFFull), hi = (int)(word >> 32);
-    w.t = rl(lo, 0); w.step_count = rl(hi, 0);
-    w.done = rl(lo, 1); w.n_unassigned = rl(hi, 1);
-    w.status = (uint32_t)rl(lo, 2); w.seq_ctr = (uint32_t)rl(hi, 2);
-    w.rng_calls = (uint32_t)rl(lo, 3); w.busy = (uint32_t)rl(hi, 3);
-    w.completion = rl(lo, 4); w.completion_last = rl(hi, 4);
-    w.tard_done = (long long)(((unsigned long long)(uint32_t)rl(hi, 5) << 32) | (uint32_t)rl(lo, 5));
-    w.delay_sum = (long long)(((unsigned long long)(uint32_t)rl(hi, 6) << 32) | (uint32_t)rl(lo, 6));
-    {   // obs_prev[i] sits in word 8+i; move it to lane i
-        const int src = (w.lane + 8) & 63;
-        const int plo = __builtin_amdgcn_ds_bpermute(src << 2, lo), phi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
-        w.obs_prev_l = __hiloint2double(phi, plo);
-    }
+    w.t = uni(sc.t); w.step_count = uni(sc.step_count); w.done = uni(sc.done); w.n_unassigned = uni(sc.n_unassigned);
+    w.status = uniu(sc.status); w.seq_ctr = uniu(sc.seq_ctr); w.rng_calls = uniu(sc.rng_calls); w.busy = uniu(sc.busy);
+    w.completion = uni(sc.completion); w.completion_last = uni(sc.completion_last);
+    w.tard_done = sc.tard_done; w.delay_sum = sc.delay_sum;
+    w.obs_prev_l = obs0;
     w.tend_m = w.lane < w.M ? tend0 : 0;
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
     if (un_lds) {
@@ -291,26 +283,14 @@ __device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
     const int KP = w.KP;
     unsigned char *er = w.er;
     wave_sync();
-    // rebuild the 18 words lane-wise
-    unsigned long long word = 0;
-    auto pk = [](uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; };
-    switch (w.lane) {
-    case 0: word = pk((uint32_t)w.t, (uint32_t)w.step_count); break;
-    case 1: word = pk((uint32_t)w.done, (uint32_t)w.n_unassigned); break;
-    case 2: word = pk(w.status, w.seq_ctr); break;
-    case 3: word = pk(w.rng_calls, w.busy); break;
-    case 4: word = pk((uint32_t)w.completion, (uint32_t)w.completion_last); break;
-    case 5: word = (unsigned long long)w.tard_done; break;
-    case 6: word = (unsigned long long)w.delay_sum; break;
-    default: break;
+    if (w.lane == 0) {
+        EnvScalars *es = reinterpret_cast<EnvScalars *>(er);
+        es->t = w.t; es->step_count = w.step_count; es->done = w.done; es->n_unassigned = w.n_unassigned;
+        es->status = w.status; es->seq_ctr = w.seq_ctr; es->rng_calls = w.rng_calls; es->busy = w.busy;
+        es->completion = w.completion; es->completion_last = w.completion_last;
+        es->tard_done = w.tard_done; es->delay_sum = w.delay_sum;
     }
-    {   // lane i < 10 holds obs_prev[i]; it belongs in word 8+i
-        const int src = (w.lane - 8) & 63;
-        const int lo = __double2loint(w.obs_prev_l), hi = __double2hiint(w.obs_prev_l);
-        const int plo = __builtin_amdgcn_ds_bpermute(src << 2, lo), phi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
-        if (w.lane >= 8 && w.lane < 18) word = pk((uint32_t)plo, (uint32_t)phi);
-    }
-    if (w.lane < 18) reinterpret_cast<unsigned long long *>(er)[w.lane] = word;
+    if (w.lane < 10) reinterpret_cast<EnvScalars *>(er)->obs_prev[w.lane] = w.obs_prev_l;
     if (w.lane < w.M) {
         reinterpret_cast<int32_t *>(er + w.e_tend)[w.lane] = w.tend_m;
         reinterpret_cast<int32_t *>(er + w.e_mjob)[w.lane] = w.mjob_m;
@@ -345,9 +325,9 @@ __device__ __forceinline__ void compute_params(W<KC> &w) {
         double max_e = 0.0, sum_e = 0.0;
         for (int n = jbeg; n < jbeg + jcnt; ++n) {
             const uint32_t js = w.jstL[n];
+            const int d = w.dueL[n];            // fetched together with the state word: one LDS latency, not two
             const int nj = (int)(js & 0xFFu);
             if (nj <= j) {
-                const int d = w.dueL[n];
                 const int da = t - d;                                   // :138
                 const double est = td + ts * (double)(idx + 1);        // :136,139
                 const double de = est - (double)d;
@@ -600,10 +580,10 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_
     const int KP = w.KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
-    const int Jr = (int)((rlu(pick<KC>(w.kB, cs), ls) >> 8) & 0xFFu);
+    const uint32_t kb = rlu(pick<KC>(w.kB, cs), ls);
+    const int Jr = (int)((kb >> 8) & 0xFFu);
     const int time_end = w.t + pm;                                           // :184
-    const uint32_t js = w.jstL[job];
-    const int nj = (int)(js & 0xFFu) + 1;
+    const int nj = (int)(kb & 0xFFu) + 1;       // the FIFO head of (r, j) is at stage j; it moves to j + 1
     if (w.lane == 0) {
         w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);                        // :186-191
         w.unp[m_sel * KP + k_sel] = un_sel - 1.0;                            // :198
@@ -611,7 +591,9 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_
 #pragma unroll
     for (int c = 0; c < KC; ++c)
         if (c == cs && w.lane == ls) w.fifo_cnt[c]--;
-    if (w.lane == m_sel) { w.tend_m = time_end; w.mjob_m = job; }           // :194-197
+    // machine lane: time_end, and job | (k of the job's next stage + 1) << 16 so that the release at the
+    // completion event (:209-215) needs no look-up (0 in the high half = the job has no further stage)
+    if (w.lane == m_sel) { w.tend_m = time_end; w.mjob_m = job | ((nj == Jr ? 0 : k_sel + 2) << 16); }   // :194-197
     w.busy |= 1u << m_sel;
     if (time_end > w.completion) w.completion = time_end;
     if (nj == Jr) {                                                          // :200-202
@@ -629,12 +611,10 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_
         while (fin) {
             const int m = __builtin_ctzll(fin);
             fin &= fin - 1;
-            const int jb = rl(w.mjob_m, m);
-            const uint32_t s2 = w.jstL[jb];
-            const uint32_t ji = w.jinfoL[jb];
-            const int n2 = (int)(s2 & 0xFFu), J2 = (int)((ji >> 16) & 0xFFu);
-            if (n2 < J2) {
-                const int kk = (int)(ji & 0xFFFFu) + n2;
+            const int mj = rl(w.mjob_m, m);
+            const int jb = mj & 0xFFFF, kk = (mj >> 16) - 1;
+            if (kk >= 0) {
+                const int n2 = (int)(rlu(pick<KC>(w.kB, kk >> 6), kk & 63) & 0xFFu);   // stage index of kk
                 if (w.lane == 0) w.jstL[jb] = jst_pack(w.seq_ctr, (uint32_t)n2);
                 w.seq_ctr++;
 #pragma unroll
