@@ -14,6 +14,7 @@ from . import _capi
 from ._capi import check
 
 VARIANT_SO_FJSSP = 0
+VARIANT_SO_SFJSP = 1
 VARIANT_MO_FJSSP_DISCRETES = 2
 
 ST_BAD_TASK_RULE = 1

@@ -79,7 +79,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     if (!s || !out || first < 0 || n_inst <= 0 || n_envs <= 0 || (size_t)first + (size_t)n_inst > s->v.size()) {
         set_error("fjsp_env_create: bad arguments"); return FJSP_E_ARG;
     }
-    if (variant != FJSP_VARIANT_SO_FJSSP && variant != FJSP_VARIANT_MO_FJSSP_DISCRETES) {
+    if (variant != FJSP_VARIANT_SO_FJSSP && variant != FJSP_VARIANT_SO_SFJSP && variant != FJSP_VARIANT_MO_FJSSP_DISCRETES) {
         set_error("fjsp_env_create: unknown variant"); return FJSP_E_ARG;
     }
     int Kmax = 0, Mmax = 0, Jmax = 0;
@@ -121,7 +121,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.JP = ((Jmax + 63) / 64) * 64;
     b.variant = variant;
     b.n_obs = variant == FJSP_VARIANT_SO_FJSSP ? 10 : 9;
-    b.n_static = variant == FJSP_VARIANT_SO_FJSSP ? 0 : 7;
+    b.n_static = variant == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 7 : 0;
     b.state_size = b.n_static + 2 * b.n_obs;
     b.rng_seed = rng_seed;
     const size_t KP = (size_t)b.KP, MP = (size_t)b.MP, JP = (size_t)b.JP, NI = (size_t)n_inst, N = (size_t)n_envs;
@@ -193,6 +193,23 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             double *ss = reinterpret_cast<double *>(ip(i, L.i_ss));
             ss[0] = in.ddt; ss[1] = (double)in.M; ss[2] = (double)in.R; ss[3] = N_ave;
             ss[4] = std::sqrt(a / (double)in.R); ss[5] = J_ave; ss[6] = std::sqrt(c2 / (double)in.R);
+        }
+        {   // fluid_completed_time = max_k Q_k / rate_k, rate_k summed over machine_rj_dict in FILE order
+            // (class_FJSSP.py:276-278); the SO_SFJSP reward divides by it (SO_SFJSP.py:220)
+            double best = 0.0;
+            bool first_k = true;
+            for (int k = 0; k < in.K; ++k) {
+                double acc = 0.0;
+                for (int q = 0; q < in.elig_n[k]; ++q) {
+                    const int m = in.elig_list[(size_t)k * in.M + q];
+                    acc = acc + in.x[(size_t)k * in.M + m] * (1.0 / (double)in.p[(size_t)k * in.M + m]);
+                }
+                int r_of_k = 0;
+                while (in.koff[r_of_k + 1] <= k) ++r_of_k;
+                const double v = (double)in.count[r_of_k] / acc;
+                if (first_k || v > best) { best = v; first_k = false; }
+            }
+            reinterpret_cast<double *>(ip(i, L.i_ss))[7] = best;
         }
         // algorithmic HBM bytes of one env-step (DESIGN.md "bytes per env-step"):
         //   static per-k rows (kinfoA/B, elig, fmask, first4 u32; rate_sum, time_sum f64)  K * 36

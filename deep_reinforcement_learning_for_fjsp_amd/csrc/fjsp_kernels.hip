@@ -31,6 +31,8 @@
 // Compiled with -ffp-contract=off: a*b+c must round twice like CPython.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/fjsp_amd.h"
 #include "fjsp_device.h"
 #include "fjsp_pyset.h"
@@ -151,13 +153,14 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 }
 
 // ------------------------------------------------------------------ wave state
-template <int KC>
+template <int KC, int V>
 struct W {
     // batch constants copied out of the kernel argument (keeping a pointer to the argument struct
     // makes the compiler spill it to scratch and re-load fields through memory)
-    int KP, JP, variant, n_obs, n_static, state_size;
+    int KP, JP, n_obs, n_static, state_size;
     uint32_t e_jst, e_tend, e_mjob, e_un;
     const double *sstate;
+    double fluid_completed_time;
     int env, inst, lane;
     // uniform instance dims
     int K, M, njobs;
@@ -196,10 +199,10 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, boo
 // Bind the wave to its records and bring the environment in.  All loads below are
 // independent of each other (bounds come from the kernel arguments, not from the
 // instance header), so they are in flight together: one memory round trip.
-template <int KC>
-__device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
+template <int KC, int V>
+__device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
                                          bool load_state) {
-    w.KP = b->KP; w.JP = b->JP; w.variant = b->variant; w.n_obs = b->n_obs; w.n_static = b->n_static;
+    w.KP = b->KP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
     w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un;
     w.env = env;
@@ -254,6 +257,7 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
     w.arr_i = reinterpret_cast<const double *>(ir + L.i_arr);
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
     w.sstate = reinterpret_cast<const double *>(ir + L.i_ss);
+    w.fluid_completed_time = w.sstate[7];
     // ---- consume
     w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
     w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
@@ -278,8 +282,8 @@ __device__ __forceinline__ void open_env(W<KC> &w, const DevBatch *b, int env, u
     wave_sync();
 }
 
-template <int KC>
-__device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
+template <int KC, int V>
+__device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
     const int KP = w.KP;
     unsigned char *er = w.er;
     wave_sync();
@@ -311,8 +315,8 @@ __device__ __forceinline__ void store_dynamic(W<KC> &w, bool un_lds) {
 // kind and keeps the same index.  job_now_list[k] is recovered from the job
 // words: jobs at stage j carrying a FIFO sequence; its head is the smallest
 // sequence (append order, SO_FJSSP.py:215, class_FJSSP.py:225).
-template <int KC>
-__device__ __forceinline__ void compute_params(W<KC> &w) {
+template <int KC, int V>
+__device__ __forceinline__ void compute_params(W<KC, V> &w) {
     const int t = w.t;
     const double td = (double)t;
 #pragma unroll
@@ -405,15 +409,15 @@ __device__ __forceinline__ int nth_bit(const uint64_t (&mask)[KC], int idx) {
     return -1;
 }
 // random.choice replacement (fjsp_oracle.h): index into a list of length n
-template <int KC>
-__device__ __forceinline__ int rng_choice(W<KC> &w, int n) {
+template <int KC, int V>
+__device__ __forceinline__ int rng_choice(W<KC, V> &w, int n) {
     const uint64_t u = splitmix64(w.env_seed + (uint64_t)w.rng_calls);
     w.rng_calls++;
     return (int)(((u >> 32) * (uint64_t)n) >> 32);
 }
 
-template <int KC>
-__device__ __forceinline__ bool any_available(const W<KC> &w, uint32_t idle) {
+template <int KC, int V>
+__device__ __forceinline__ bool any_available(const W<KC, V> &w, uint32_t idle) {
     uint64_t any = 0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) any |= __ballot(w.fifo_cnt[c] > 0 && (w.elig[c] & idle) != 0);
@@ -422,15 +426,15 @@ __device__ __forceinline__ bool any_available(const W<KC> &w, uint32_t idle) {
 
 // fluid_unprocessed_number (SO_FJSSP.py:239-240) is a pure function of the clock
 // (order_arrive_time = 0 for a single order): Q0 - rate_sum * t.
-template <int KC>
-__device__ __forceinline__ double fluid_q(const W<KC> &w, int c) {
+template <int KC, int V>
+__device__ __forceinline__ double fluid_q(const W<KC, V> &w, int c) {
     const double q0 = (double)(w.kA[c] >> 16);
     return q0 - w.rate_sum[c] * (double)w.t;
 }
 
 // SO_FJSSP.py:267-298 task_select.  Returns k or -1 (status set).
-template <int KC>
-__device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
+template <int KC, int V>
+__device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
     uint64_t av[KC], fav[KC];
     uint64_t anyav = 0, anyfav = 0;
 #pragma unroll
@@ -441,6 +445,32 @@ __device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
         anyav |= av[c]; anyfav |= fav[c];
     }
     if (!anyav) { w.status |= FJSP_ST_NO_EVENT; return -1; }
+    if (V == FJSP_VARIANT_SO_SFJSP) {                 // SO_SFJSP.py:169-188
+        if (a0 == 0) {                                        // rule 1: argmax Tasks.gap
+            double gap[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) gap[c] = (double)w.nun[c] - fluid_q(w, c);
+            return anyfav ? argmax_f64<KC>(fav, gap) : argmax_f64<KC>(av, gap);
+        }
+        if (a0 == 1 || a0 == 2) {                             // rules 2, 3: argmin time_min[_fluid]_rj (:234-244)
+            const bool fluid = a0 == 1 && anyfav;
+            int tmin[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const uint32_t cand = idle & (fluid ? w.fmask[c] : w.elig[c]);
+                int best = 0x7fffffff;
+                for (int m = 0; m < w.M; ++m) {
+                    const int pv = w.p_i[m * w.KP + c * kWave + w.lane];
+                    if (((cand >> m) & 1u) && pv < best) best = pv;
+                }
+                tmin[c] = best;
+            }
+            return fluid ? argext_i32<KC, false>(fav, tmin) : argext_i32<KC, false>(av, tmin);
+        }
+        if (a0 == 3) return nth_bit<KC>(av, rng_choice(w, popc_masks<KC>(av)));   // rule 4
+        w.status |= FJSP_ST_BAD_TASK_RULE;
+        return -1;
+    }
     // kind_task_delivery_urgency (:153) = sum(estimated delays) / len(list); only rules 1, 2, 4 read it
     double urg[KC];
     if (a0 == 0 || a0 == 1 || a0 == 3) {
@@ -483,8 +513,8 @@ __device__ __forceinline__ int task_select(W<KC> &w, int a0, uint32_t idle) {
 
 // Machine.gap_ave (class_FJSSP.py:144-146) for one machine: serial sum over
 // kind_task_tuple order of unprocessed - fluid_unprocessed, divided by (n + 1e-18).
-template <int KC>
-__device__ __forceinline__ double machine_gap_ave(const W<KC> &w, int m) {
+template <int KC, int V>
+__device__ __forceinline__ double machine_gap_ave(const W<KC, V> &w, int m) {
     const int KP = w.KP;
     const double dt = (double)w.t;
     double s = 0.0;
@@ -508,8 +538,8 @@ __device__ __forceinline__ double machine_gap_ave(const W<KC> &w, int m) {
 
 // SO_FJSSP.py:300-322 machine_select.  Candidate lists are visited in CPython's
 // list(set & set) order (fjsp_pyset.h): ascending for M <= 8, not always beyond.
-template <int KC>
-__device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel) {
+template <int KC, int V>
+__device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel) {
     const int KP = w.KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const uint32_t elig_s = rlu(pick<KC>(w.elig, cs), ls), fm_s = rlu(pick<KC>(w.fmask, cs), ls);
@@ -543,11 +573,22 @@ __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint3
     auto argmax_gave = [&](const CandList &l) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
         int best = -1; double bv = 0.0;
-        visit(l, [&](int m) { const double v = machine_gap_ave<KC>(w, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        visit(l, [&](int m) { const double v = machine_gap_ave<KC, V>(w, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
     int m_sel;
-    if (w.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
+    if (V == FJSP_VARIANT_SO_SFJSP) {
+        switch (a1) {                                             // SO_SFJSP.py:190-214
+        case 0: m_sel = argmax_gap(fsel.n ? fsel : sel); break;
+        case 1: m_sel = argmin_p(fsel.n ? fsel : sel); break;
+        case 2: m_sel = argmin_p(sel); break;
+        case 3: m_sel = argmax_gave(fsel.n ? fsel : sel); break;
+        case 4: m_sel = cand_at(sel, rng_choice(w, sel.n)); break;
+        default:
+            w.status |= FJSP_ST_BAD_MACHINE_RULE;
+            return -1;
+        }
+    } else if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
         switch (a1) {                                             // MO_FJSSP_discretes.py:209-230
         case 0: m_sel = fsel.n ? argmax_gap(fsel) : argmin_p(sel); break;       // rule 1 :213-217
         case 1: m_sel = argmax_gave(fsel.n ? fsel : sel); break;                // rule 2 :218-222
@@ -575,8 +616,8 @@ __device__ __forceinline__ int machine_select(W<KC> &w, int a1, int k_sel, uint3
 
 // SO_FJSSP.py:176-250: dispatch the FIFO head of k_sel on m_sel, then advance
 // the clock until some operation type is available again (or the episode ends).
-template <int KC>
-__device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_sel, int pm, double un_sel) {
+template <int KC, int V>
+__device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, int k_sel, int m_sel, int pm, double un_sel) {
     const int KP = w.KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
@@ -602,7 +643,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_
         w.tard_done += late > 0 ? late : 0;
     }
     uint32_t idle = ~w.busy & w.mmask;
-    while (!any_available<KC>(w, idle)) {                                    // :204
+    while (!any_available<KC, V>(w, idle)) {                                    // :204
         const int cand = (w.lane < w.M && w.tend_m > w.t) ? w.tend_m : 0x7fffffff;
         const int tn = wave_min(cand);                                       // :205-207 next event
         if (tn == 0x7fffffff) { w.status |= FJSP_ST_NO_EVENT; break; }
@@ -638,8 +679,8 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC> &w, int k_sel, int m_
 // gap_rate, every other lane: finish_rate; then all lanes: machine time_end), so
 // the chains cost one LDS read + one add per element instead of cross-lane traffic,
 // and two chains advance per instruction.
-template <int KC>
-__device__ __forceinline__ long long observe(W<KC> &w) {
+template <int KC, int V>
+__device__ __forceinline__ long long observe(W<KC, V> &w) {
     const int K = w.K, M = w.M;
     // ---- integer statistics (order-free): packed DPP reductions (totals < 65536, checked at create)
     uint32_t nun_s = 0, a_s = 0, e_s = 0, ja_s = 0, je_s = 0;
@@ -693,6 +734,71 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
     wave_sync();
     const double sd = sqrt(lds_chain_sum(src_off, n8) / len);
     const double cro_ave = ave_fr, cro_std = rld(sd, 0), gap_ave = ave_gr, gap_std = rld(sd, 1), ct_std = rld(sd, 2);
+    if (V == FJSP_VARIANT_SO_SFJSP) {
+        // SO_SFJSP.py:64-83: [M_idle_ratio, ct_std, cro_ave, cro_std, ratio_idle, gap_ave, gap_std, gap_m_ave, gap_m_std]
+        const uint32_t idle = ~w.busy & w.mmask;
+        int nav = 0, nfav = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const bool has = w.fifo_cnt[c] > 0;
+            nav += __builtin_popcountll(__ballot(has && (w.elig[c] & idle) != 0));
+            nfav += __builtin_popcountll(__ballot(has && (w.fmask[c] & idle) != 0));
+        }
+        const double m_idle_ratio = (double)__builtin_popcount(idle) / (double)M;
+        const double ratio_idle = (double)nfav / ((double)nav + 1e-08);
+        // Machine.gap_ave of EVERY machine (class_FJSSP.py:144-146), three machines per pass: their gap rows
+        // (ineligible entries +0.0, an exact identity of the running sum) go to the three LDS rows and lanes
+        // 0..2 walk one row each.  In the step kernel the unprocessed matrix lives in HBM and lane 0 has just
+        // updated one element of it, so that store is drained first.
+        wave_sync_global();
+        const int KP = w.KP;
+        const double dt = (double)w.t;
+        double gave_m = 0.0;                       // lane m (< M): gap_ave of machine m
+        for (int m0 = 0; m0 < M; m0 += 3) {
+            int cnt_q[3] = {0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int m = m0 + q;
+                double *row = q == 0 ? w.frL : (q == 1 ? w.grL : w.tdL);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const int k = c * kWave + w.lane;
+                    int pm = 0;
+                    double g = 0.0;
+                    if (m < M) {
+                        pm = w.p_i[m * KP + k];
+                        if (pm > 0) g = w.unp[m * KP + k] - (w.arr_i[m * KP + k] - dt * w.rate_i[m * KP + k]);
+                    }
+                    row[k] = g;
+                    cnt_q[q] += __builtin_popcountll(__ballot(pm > 0));
+                }
+            }
+            wave_sync();
+            const double sm = lds_chain_sum(src_off, n8);
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double v = rld(sm, q) / ((double)cnt_q[q] + 1e-18);
+                if (w.lane == m0 + q) gave_m = v;
+            }
+        }
+        // gap_m_ave / gap_m_std over machines in ascending order (:78-80)
+        if (w.lane < (uint32_t)w.KP) w.tdL[w.lane] = w.lane < M ? gave_m : 0.0;
+        wave_sync();
+        const uint32_t td_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.tdL) - fjsp_lds);
+        const int m8 = (M + 7) & ~7;
+        const double gm_ave = lds_chain_sum(td_off, m8) / (double)M;
+        wave_sync();
+        { const double d = gave_m - gm_ave; if (w.lane < (uint32_t)w.KP) w.tdL[w.lane] = w.lane < M ? d * d : 0.0; }
+        wave_sync();
+        const double gm_std = sqrt(lds_chain_sum(td_off, m8) / (double)M);
+        if (w.lane == 0) {
+            w.scrL[0] = m_idle_ratio; w.scrL[1] = ct_std; w.scrL[2] = cro_ave; w.scrL[3] = cro_std; w.scrL[4] = ratio_idle;
+            w.scrL[5] = gap_ave; w.scrL[6] = gap_std; w.scrL[7] = gm_ave; w.scrL[8] = gm_std;
+        }
+        wave_sync();
+        return 0;          // this subclass never calls update_parameter: delay_time_sum_unprocessed stays 0
+    }
     double dro_a = 0.0, dro_e = 0.0, drj_a = 0.0, drj_e = 0.0;
     if (!w.done) {                                                           // :156-165
         dro_a = (double)delay_a / (double)task_number; dro_e = (double)delay_e / (double)task_number;
@@ -700,7 +806,7 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
     }
     if (w.lane == 0) {
         int i = 0;
-        if (w.variant == FJSP_VARIANT_SO_FJSSP) w.scrL[i++] = (double)M;
+        if (V == FJSP_VARIANT_SO_FJSSP) w.scrL[i++] = (double)M;
         w.scrL[i++] = ct_std; w.scrL[i++] = cro_ave; w.scrL[i++] = cro_std; w.scrL[i++] = gap_ave;
         w.scrL[i++] = gap_std; w.scrL[i++] = dro_a; w.scrL[i++] = dro_e; w.scrL[i++] = drj_a; w.scrL[i++] = drj_e;
     }
@@ -709,8 +815,8 @@ __device__ __forceinline__ long long observe(W<KC> &w) {
 }
 
 // state = [static, v(t), v(t) - v(t-1)]  (SO_FJSSP.py:71-72,257-258); updates obs_prev.
-template <int KC>
-__device__ __forceinline__ void emit_state(W<KC> &w, double *state_out, bool zero_gap) {
+template <int KC, int V>
+__device__ __forceinline__ void emit_state(W<KC, V> &w, double *state_out, bool zero_gap) {
     const int n_obs = w.n_obs, n_static = w.n_static;
     const double cur = w.lane < n_obs ? w.scrL[w.lane] : 0.0;
     const double gap = zero_gap ? cur - cur : cur - w.obs_prev_l;
@@ -724,8 +830,8 @@ __device__ __forceinline__ void emit_state(W<KC> &w, double *state_out, bool zer
 }
 
 // SO_FJSSP.py:51-76 reset (fresh-object semantics; class_FJSSP.py:173-244 for one order).
-template <int KC>
-__device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
+template <int KC, int V>
+__device__ __forceinline__ void init_episode(W<KC, V> &w, double *state_out) {
     const int KP = w.KP;
     w.t = 0; w.step_count = 0; w.done = 0; w.n_unassigned = w.njobs; w.status = 0;
     w.seq_ctr = (uint32_t)w.njobs; w.busy = 0; w.completion = 0; w.completion_last = 0;
@@ -737,43 +843,46 @@ __device__ __forceinline__ void init_episode(W<KC> &w, double *state_out) {
         for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = w.arr_i[m * KP + c * kWave + w.lane];
     wave_sync();
     wave_sync_global();       // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
-    compute_params<KC>(w);
-    observe<KC>(w);                      // delay_time_sum_unprocessed is 0-relevant only after a step
-    emit_state<KC>(w, state_out, true);
+    compute_params<KC, V>(w);
+    observe<KC, V>(w);                      // delay_time_sum_unprocessed is 0-relevant only after a step
+    emit_state<KC, V>(w, state_out, true);
 }
 
 // One environment step.  compute_params() must be current on entry and is
 // current again on exit (the fused kernel carries it across steps).
-template <int KC>
-__device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, const double *mo, double *state_out, int *k_out,
+template <int KC, int V>
+__device__ __forceinline__ double env_step(W<KC, V> &w, int a0, int a1, const double *mo, double *state_out, int *k_out,
                                            int *m_out) {
-    const bool is_mo = w.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES;
+    const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
         if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }   // IndexError
         a1 = a0 % 3; a0 = a0 / 3;
+    } else if (is_sf) {              // SO_SFJSP.py:25,87-88
+        if (a0 >= 20) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }
+        a1 = a0 % 5; a0 = a0 / 5;
     }
     const uint32_t idle = ~w.busy & w.mmask;
-    const int k_sel = task_select<KC>(w, a0, idle);
+    const int k_sel = task_select<KC, V>(w, a0, idle);
     STAMP(w, 2);
     int pm = 0;
     double un_sel = 0.0;
-    const int m_sel = k_sel >= 0 ? machine_select<KC>(w, a1, k_sel, idle, &pm, &un_sel) : -1;
+    const int m_sel = k_sel >= 0 ? machine_select<KC, V>(w, a1, k_sel, idle, &pm, &un_sel) : -1;
     STAMP(w, 3);
     *k_out = k_sel; *m_out = m_sel;
     if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
-    dispatch_and_advance<KC>(w, k_sel, m_sel, pm, un_sel);
+    dispatch_and_advance<KC, V>(w, k_sel, m_sel, pm, un_sel);
     STAMP(w, 4);
     w.step_count++;                                                          // :252
-    compute_params<KC>(w);
+    compute_params<KC, V>(w);
     STAMP(w, 5);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 2
     const long long tard_unproc = 0;            // diagnostic: no observation
 #elif defined(FJSP_ABLATE) && FJSP_ABLATE == 1
-    const long long tard_unproc = observe<KC>(w);   // diagnostic: observation computed, not emitted
+    const long long tard_unproc = observe<KC, V>(w);   // diagnostic: observation computed, not emitted
 #else
-    const long long tard_unproc = observe<KC>(w);                           // :256
+    const long long tard_unproc = observe<KC, V>(w);                           // :256
     STAMP(w, 6);
-    emit_state<KC>(w, state_out, false);
+    emit_state<KC, V>(w, state_out, false);
     STAMP(w, 7);
 #endif
     const long long delay_new = w.tard_done + tard_unproc;                   // :259
@@ -781,6 +890,7 @@ __device__ __forceinline__ double env_step(W<KC> &w, int a0, int a1, const doubl
     const int dc = w.completion_last - w.completion;
     w.delay_sum = delay_new;                                                 // :263
     w.completion_last = w.completion;
+    if (is_sf) return (double)dc / w.fluid_completed_time;                   // SO_SFJSP.py:216-220 (dc = -(C - C_last))
     if (!is_mo) return (double)(-delta);                                     // :328 (exact integer)
     // MO_FJSSP_discretes.py:232-244 compute_reward(weight_vector, completion, tardiness)
     const double w0 = mo ? mo[0] : 0.0, w1 = mo ? mo[1] : 1.0, cn = mo ? mo[2] : 0.0, tn = mo ? mo[3] : 0.0;
@@ -827,22 +937,22 @@ __global__ void fluid_tables_kernel(DevBatch b) {
     }
 }
 
-template <int KC>
+template <int KC, int V>
 __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *mask, double *state_out) {
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
     if (mask && mask[env] == 0) return;
-    W<KC> w;
-    open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, false);
+    W<KC, V> w;
+    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, false);
     // rng_calls survives a reset (the reference's global `random` state does too)
     w.rng_calls = env_ptr<const EnvScalars>(b, env, 0)->rng_calls;
     w.obs_prev_l = 0.0;
-    init_episode<KC>(w, state_out);
-    store_dynamic<KC>(w, false);
+    init_episode<KC, V>(w, state_out);
+    store_dynamic<KC, V>(w, false);
 }
 
-template <int KC>
+template <int KC, int V>
 __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
                                                       double *state_out, double *reward_out, uint8_t *done_out,
                                                       int16_t *trace_km) {
@@ -852,13 +962,13 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
 #if defined(FJSP_ABLATE) && FJSP_ABLATE >= 5
     return;                                     // diagnostic: launch overhead only
 #endif
-    W<KC> w;
+    W<KC, V> w;
     STAMP_BEGIN(w);
     const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
-    open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
+    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
     STAMP(w, 0);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE >= 4
-    store_dynamic<KC>(w, false);                // diagnostic: state in / state out only
+    store_dynamic<KC, V>(w, false);                // diagnostic: state in / state out only
     return;
 #endif
     if (w.done) {
@@ -872,37 +982,37 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
             }
             return;
         }
-        init_episode<KC>(w, nullptr);
+        init_episode<KC, V>(w, nullptr);
     } else {
-        compute_params<KC>(w);
+        compute_params<KC, V>(w);
     }
     STAMP(w, 1);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE >= 3
-    store_dynamic<KC>(w, false);                // diagnostic: + compute_params
+    store_dynamic<KC, V>(w, false);                // diagnostic: + compute_params
     return;
 #endif
     int k_sel, m_sel;
-    const double reward = env_step<KC>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
+    const double reward = env_step<KC, V>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
     if (w.lane == 0) {
         if (reward_out) reward_out[env] = reward;
         if (done_out) done_out[env] = (uint8_t)w.done;
         if (trace_km) { trace_km[(size_t)env * 2] = (int16_t)k_sel; trace_km[(size_t)env * 2 + 1] = (int16_t)m_sel; }
     }
-    store_dynamic<KC>(w, false);
+    store_dynamic<KC, V>(w, false);
     STAMP(w, 8);
     STAMP_FLUSH(w);
 }
 
 // T fused steps per launch: the environment lives in registers + LDS for the whole episode.
-template <int KC>
+template <int KC, int V>
 __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T,
                                                       int16_t *trace_km, double *reward_out, double *state_last) {
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
-    W<KC> w;
-    open_env<KC>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, true), true, true);
-    compute_params<KC>(w);
+    W<KC, V> w;
+    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, true), true, true);
+    compute_params<KC, V>(w);
     for (int s = 0; s < T; ++s) {
         const size_t o = (size_t)s * b.N + env;
         int k_sel = -1, m_sel = -1;
@@ -910,14 +1020,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t 
         const bool live = !w.done && !(w.status & (FJSP_ST_BAD_TASK_RULE | FJSP_ST_BAD_MACHINE_RULE | FJSP_ST_NO_EVENT));
         if (live) {
             const int a0 = actions[o * 2], a1 = actions[o * 2 + 1];
-            reward = env_step<KC>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel);
+            reward = env_step<KC, V>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel);
         }
         if (w.lane == 0) {
             if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }
             if (reward_out) reward_out[o] = reward;
         }
     }
-    store_dynamic<KC>(w, true);
+    store_dynamic<KC, V>(w, true);
 }
 
 // attribute read-back: one thread per environment
@@ -948,37 +1058,56 @@ int launch_fluid_tables(const DevBatch &b, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-#define DISPATCH_KC(kc, CALL)                     \
-    switch (kc) {                                 \
-    case 1: { constexpr int KC = 1; CALL; } break; \
-    case 2: { constexpr int KC = 2; CALL; } break; \
-    case 4: { constexpr int KC = 4; CALL; } break; \
-    default: return -1;                           \
+// one instantiation per (chunk count, environment variant): the variant is a compile-time
+// parameter so SO_FJSSP's kernels carry none of the subclasses' code or registers
+template <int V, class F>
+static int dispatch_kc(int kc, F &&f) {
+    switch (kc) {
+    case 1: f(std::integral_constant<int, 1>{}, std::integral_constant<int, V>{}); return 0;
+    case 2: f(std::integral_constant<int, 2>{}, std::integral_constant<int, V>{}); return 0;
+    case 4: f(std::integral_constant<int, 4>{}, std::integral_constant<int, V>{}); return 0;
+    default: return -1;
     }
+}
+template <class F>
+static int dispatch(const DevBatch &b, F &&f) {
+    switch (b.variant) {
+    case FJSP_VARIANT_SO_FJSSP: return dispatch_kc<FJSP_VARIANT_SO_FJSSP>(b.KC, f);
+    case FJSP_VARIANT_SO_SFJSP: return dispatch_kc<FJSP_VARIANT_SO_SFJSP>(b.KC, f);
+    case FJSP_VARIANT_MO_FJSSP_DISCRETES: return dispatch_kc<FJSP_VARIANT_MO_FJSSP_DISCRETES>(b.KC, f);
+    default: return -1;
+    }
+}
 
 int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStream_t st) {
     const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
-    DISPATCH_KC(b.KC, hipLaunchKernelGGL((reset_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, mask, state));
+    if (dispatch(b, [&](auto kc, auto v) {
+            hipLaunchKernelGGL((reset_kernel<decltype(kc)::value, decltype(v)::value>), grid_for(b.N), dim3(256), lds, st, b,
+                               mask, state);
+        }) != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                 uint8_t *done, int16_t *trace_km, hipStream_t st) {
     const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
-    DISPATCH_KC(b.KC, hipLaunchKernelGGL((step_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, autoreset,
-                                         state, reward, done, trace_km));
+    if (dispatch(b, [&](auto kc, auto v) {
+            hipLaunchKernelGGL((step_kernel<decltype(kc)::value, decltype(v)::value>), grid_for(b.N), dim3(256), lds, st, b,
+                               actions, mo, autoreset, state, reward, done, trace_km);
+        }) != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 size_t rollout_lds_bytes(const DevBatch &b) { return 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, true); }
 int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st) {
     const size_t lds = rollout_lds_bytes(b);
-    DISPATCH_KC(b.KC, {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<KC>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((rollout_kernel<KC>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, T, trace_km, reward,
-                           state_last);
-    });
+    if (dispatch(b, [&](auto kc, auto v) {
+            constexpr int KC = decltype(kc)::value, V = decltype(v)::value;
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<KC, V>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((rollout_kernel<KC, V>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, T, trace_km, reward,
+                               state_last);
+        }) != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -1,2 +1,3 @@
 from .SO_FJSSP import SO_FJSSP_Environment, BatchedSOFJSSP  # noqa: F401
 from .MO_FJSSP_discretes import MO_FJSSP_Environment, BatchedMOFJSSP  # noqa: F401
+from .SO_SFJSP import SO_SFJSP_Environment, BatchedSOSFJSP  # noqa: F401

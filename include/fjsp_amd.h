@@ -52,6 +52,7 @@ enum {
 /* environment variants sharing the SO_FJSSP skeleton */
 enum {
     FJSP_VARIANT_SO_FJSSP = 0,          /* environments/SO_FJSSP.py (pair action [6,5], 20-dim state) */
+    FJSP_VARIANT_SO_SFJSP = 1,          /* environments/SO_SFJSP.py (flat 20 = 4x5, 18-dim state, makespan)  */
     FJSP_VARIANT_MO_FJSSP_DISCRETES = 2 /* environments/MO_FJSSP_discretes.py (flat 18, 25-dim state)  */
 };
 
@@ -125,7 +126,7 @@ int  fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int
                      int32_t variant, int32_t device, uint64_t rng_seed, fjsp_env **out);
 void fjsp_env_destroy(fjsp_env *e);
 int  fjsp_env_num_envs(const fjsp_env *e);
-int  fjsp_env_state_size(const fjsp_env *e);   /* 20 (SO_FJSSP) / 25 (MO_FJSSP_discretes) */
+int  fjsp_env_state_size(const fjsp_env *e);   /* 20 (SO_FJSSP) / 18 (SO_SFJSP) / 25 (MO_FJSSP_discretes) */
 int  fjsp_env_device(const fjsp_env *e);
 
 /* reset(): SO_FJSSP.py:51-76.  d_mask (u8[N], nullable): reset only envs with
@@ -133,8 +134,9 @@ int  fjsp_env_device(const fjsp_env *e);
 int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *stream);
 
 /* step(action): SO_FJSSP.py:168-265.  d_actions u8[N][2] = (task rule, machine
- * rule) indices as the reference's action pair (:171-172); for the MO variant
- * d_actions[..][0] is the flat action and d_mo (f64[N][4] = w0, w1, completion,
+ * rule) indices as the reference's action pair (:171-172); for the flat-action
+ * variants (SO_SFJSP, MO_FJSSP_discretes) d_actions[..][0] is the flat action;
+ * for the MO variant d_mo (f64[N][4] = w0, w1, completion,
  * tardiness; <=0 = None; nullable) carries step()'s extra arguments
  * (MO_FJSSP_discretes.py:88).  Outputs (all nullable): d_state f64[N][S],
  * d_reward f64[N], d_done u8[N].  Envs already done are left untouched and get

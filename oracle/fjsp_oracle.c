@@ -195,7 +195,7 @@ static int rng_choice(fjo_env *e, int n) {
 static long py_round(double v) { return (long)nearbyint(v); }
 
 fjo_env *fjo_create(const fjo_instance *in, int variant) {
-    if (variant != FJO_SO_FJSSP && variant != FJO_MO_FJSSP_DISCRETES) return NULL;
+    if (variant != FJO_SO_FJSSP && variant != FJO_SO_SFJSP && variant != FJO_MO_FJSSP_DISCRETES) return NULL;
     fjo_env *e = (fjo_env *)calloc(1, sizeof(*e));
     e->variant = variant;
     e->R = in->R; e->M = in->M; e->K = in->K; e->S = in->S;
@@ -241,6 +241,7 @@ fjo_env *fjo_create(const fjo_instance *in, int variant) {
     e->due_min = (int *)calloc((size_t)K, sizeof(int));
     e->n_obs = 10; e->n_static = 0;
     if (variant == FJO_MO_FJSSP_DISCRETES) { e->n_obs = 9; e->n_static = 7; }
+    if (variant == FJO_SO_SFJSP) { e->n_obs = 9; e->n_static = 0; }
     return e;
 }
 
@@ -461,6 +462,22 @@ static void state_extract(fjo_env *e, double *o) {
     double s = 0.0;
     for (int m = 0; m < M; ++m) s = s + pow((double)e->tend[m] - ct_m_ave, 2.0);
     double ct_m_std = sqrt(s / (double)M);
+    if (e->variant == FJO_SO_SFJSP) {                                           /* SO_SFJSP.py:64-83 */
+        int tmp[4096];
+        double M_idle_ratio = (double)machine_idle_list(e, tmp) / (double)M;
+        double ratio_idle = (double)available_list(e, 1, tmp) / ((double)available_list(e, 0, tmp) + 1e-08);
+        double cro_a = mean_k(e, tasks_finish_rate), cro_s = pop_std_k(e, tasks_finish_rate, cro_a);
+        double gap_a = mean_k(e, tasks_gap_rate), gap_s = pop_std_k(e, tasks_gap_rate, gap_a);
+        double gs = 0.0;
+        for (int m = 0; m < M; ++m) gs = gs + machine_gap_ave(e, m);
+        double gap_m_ave = gs / (double)M;
+        double g2 = 0.0;
+        for (int m = 0; m < M; ++m) g2 = g2 + pow(machine_gap_ave(e, m) - gap_m_ave, 2.0);
+        double gap_m_std = sqrt(g2 / (double)M);
+        o[0] = M_idle_ratio; o[1] = ct_m_std; o[2] = cro_a; o[3] = cro_s; o[4] = ratio_idle;
+        o[5] = gap_a; o[6] = gap_s; o[7] = gap_m_ave; o[8] = gap_m_std;
+        return;                               /* no update_parameter() call in this subclass */
+    }
     double cro_ave = mean_k(e, tasks_finish_rate), cro_std = pop_std_k(e, tasks_finish_rate, cro_ave);
     double gap_ave = mean_k(e, tasks_gap_rate), gap_std = pop_std_k(e, tasks_gap_rate, gap_ave);
     double dro_a, dro_e, drj_a, drj_e;
@@ -508,11 +525,41 @@ int fjo_reset(fjo_env *e, double *state) {
     return 0;
 }
 
+/* SO_SFJSP.py:234-244 time_min_rj / time_min_fluid_rj: min processing time of k over the idle
+ * machines of its (fluid) machine list, first minimum in list(set & set) order */
+static int time_min_rj(fjo_env *e, int k, int fluid) {
+    int idle[1024], sel[1024];
+    int nidle = machine_idle_list(e, idle);
+    int n = fluid ? fjo_pyset_and_list(idle, nidle, &e->fl_list[k * e->M], e->fl_n[k], sel)
+                  : fjo_pyset_and_list(idle, nidle, &e->elig_list[k * e->M], e->elig_n[k], sel);
+    int best = e->p[k * e->M + sel[0]];
+    for (int i = 1; i < n; ++i) if (e->p[k * e->M + sel[i]] < best) best = e->p[k * e->M + sel[i]];
+    return best;
+}
+
 /* SO_FJSSP.py:267-298 task_select.  Returns k or <0 (MyError). */
 static int task_select(fjo_env *e, int rule) {
     int av[4096], fav[4096];
     int nav = available_list(e, 0, av);
     if (nav == 0) return -3;
+    if (e->variant == FJO_SO_SFJSP) {                                           /* SO_SFJSP.py:169-188 */
+        int nf = available_list(e, 1, fav);
+        switch (rule) {
+        case 1: {
+            const int *l = nf ? fav : av; int n = nf ? nf : nav;
+            int b = l[0]; double bv = tasks_gap(e, b);
+            for (int i = 1; i < n; ++i) { double v = tasks_gap(e, l[i]); if (v > bv) { bv = v; b = l[i]; } }
+            return b; }
+        case 2: case 3: {
+            int fluid = (rule == 2 && nf > 0);
+            const int *l = fluid ? fav : av; int n = fluid ? nf : nav;
+            int b = -1, bv = 0;
+            for (int i = 0; i < n; ++i) { int v = time_min_rj(e, l[i], fluid); if (b < 0 || v < bv) { bv = v; b = l[i]; } }
+            return b; }
+        case 4: return av[rng_choice(e, nav)];
+        default: return -1;
+        }
+    }
 #define ARGMAX_D(list, n, key) ({ int _b = (list)[0]; double _bv = (key)[_b]; \
         for (int _i = 1; _i < (n); ++_i) { int _c = (list)[_i]; if ((key)[_c] > _bv) { _bv = (key)[_c]; _b = _c; } } _b; })
     switch (rule) {
@@ -567,6 +614,16 @@ static int machine_select(fjo_env *e, int rule, int k) {
         case 1: return nfs == 0 ? ARGMIN_P(sel, nsel) : ARGMAX_GAP(fsel, nfs);
         case 2: return nfs == 0 ? ARGMAX_GAVE(sel, nsel) : ARGMAX_GAVE(fsel, nfs);
         case 3: return nfs == 0 ? ARGMAX_GAP(sel, nsel) : ARGMAX_GAP(fsel, nfs);
+        default: return -2;
+        }
+    }
+    if (e->variant == FJO_SO_SFJSP) {                                           /* SO_SFJSP.py:190-214 */
+        switch (rule) {
+        case 1: return nfs == 0 ? ARGMAX_GAP(sel, nsel) : ARGMAX_GAP(fsel, nfs);
+        case 2: return nfs == 0 ? ARGMIN_P(sel, nsel) : ARGMIN_P(fsel, nfs);
+        case 3: return ARGMIN_P(sel, nsel);
+        case 4: return nfs == 0 ? ARGMAX_GAVE(sel, nsel) : ARGMAX_GAVE(fsel, nfs);
+        case 5: return sel[rng_choice(e, nsel)];
         default: return -2;
         }
     }
@@ -688,6 +745,21 @@ int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion,
     return 0;
 }
 void fjo_set_ddt(fjo_env *e, double ddt) { e->static_state[0] = ddt; }
+
+/* SO_SFJSP.py:85-167 step(action): actions table :25 = (task_rule in range(4)) x (machine_rule in range(5));
+ * reward :216-222 = -(completion_time - completion_time_last) / fluid_completed_time.
+ * state_extract of this subclass never calls update_parameter, so delay_time_sum counts finished jobs only. */
+int fjo_step_sf(fjo_env *e, int action, double *state, double *reward, int *done, fjo_trace *tr) {
+    if (e->variant != FJO_SO_SFJSP) return -6;
+    if (action < 0 || action >= 20) return -1;
+    int rc = step_core(e, action / 5 + 1, action % 5 + 1, state, tr);
+    if (rc) return rc;
+    *reward = (double)(-(e->completion_time - e->completion_time_last)) / e->fluid_completed_time;
+    e->delay_sum_last = e->delay_sum;
+    e->completion_time_last = e->completion_time;
+    *done = e->done;
+    return 0;
+}
 
 
 /* reset + play actions[t][2] until done (or max_T), all in C: the cpu_baseline timing loop */

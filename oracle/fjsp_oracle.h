@@ -51,7 +51,7 @@ typedef struct {
 } fjo_trace;
 
 /* Variants share one skeleton. */
-enum { FJO_SO_FJSSP = 0, FJO_MO_FJSSP_DISCRETES = 2 };
+enum { FJO_SO_FJSSP = 0, FJO_SO_SFJSP = 1, FJO_MO_FJSSP_DISCRETES = 2 };
 
 fjo_env *fjo_create(const fjo_instance *inst, int variant);
 void     fjo_destroy(fjo_env *e);
@@ -70,6 +70,8 @@ int fjo_step(fjo_env *e, int a0, int a1, double *state, double *reward, int *don
  * completion/tardiness <= 0 stand for None. */
 int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion, double tardiness,
                 double *state, double *reward, int *done, fjo_trace *tr);
+/* SO_SFJSP.py:85 step(action): flat action in [0, 20). */
+int fjo_step_sf(fjo_env *e, int action, double *state, double *reward, int *done, fjo_trace *tr);
 /* self.DDT as the instance source parsed it (static state element 0 of the MO variant). */
 void fjo_set_ddt(fjo_env *e, double ddt);
 

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libfjsp_oracle.so")
 
 SO_FJSSP = 0
+SO_SFJSP = 1
 MO_FJSSP_DISCRETES = 2
 
 
@@ -50,6 +51,8 @@ def lib():
                                C.POINTER(Trace)]
         L.fjo_step_mo.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(Trace)]
+        L.fjo_step_sf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                  C.POINTER(Trace)]
         for name in ("fjo_step_time", "fjo_step_count", "fjo_makespan", "fjo_completion_time"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = C.c_int
@@ -149,6 +152,16 @@ class OracleEnv(object):
                                 st.ctypes.data, C.byref(rew), C.byref(done), C.byref(tr))
         if rc:
             raise RuntimeError("oracle step_mo failed rc=%d" % rc)
+        self.done = bool(done.value)
+        self.trace = tr
+        return st, rew.value, self.done
+
+    def step_sf(self, action):
+        st = np.zeros(self.state_size)
+        rew, done, tr = C.c_double(), C.c_int(), Trace()
+        rc = self.L.fjo_step_sf(self.h, int(action), st.ctypes.data, C.byref(rew), C.byref(done), C.byref(tr))
+        if rc:
+            raise RuntimeError("oracle step_sf failed rc=%d" % rc)
         self.done = bool(done.value)
         self.trace = tr
         return st, rew.value, self.done

@@ -210,6 +210,8 @@ def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, ch
             t0 = time.perf_counter()
             if mo is None:
                 s, r, d = env.step([int(a[0]), int(a[1])])
+            elif mo == "sf":
+                s, r, d = env.step(int(a[0]))
             else:
                 s, r, d = env.step(int(a[0]), weight_vector=(mo[0], mo[1]), completion=mo[2], tardiness=mo[3])
             el += time.perf_counter() - t0
@@ -238,6 +240,8 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
     lp = lambda Q, now: fi.fluid_lp(arr.Jr, arr.p, Q, now)[0]
     if mo is None:
         env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_FJSSP, rng_seed)
+    elif mo == "sf":
+        env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_SFJSP, rng_seed)
     else:
         env = pyoracle.OracleEnv(arr, lp, pyoracle.MO_FJSSP_DISCRETES, rng_seed, ddt=arr.ddt)
     rec = {"k": [], "m": [], "job_r": [], "job_n": [], "reward": [], "done": [], "step_time": [], "delay": [],
@@ -247,6 +251,8 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
     while not env.done:
         if mo is None:
             s, r, d = env.step(actions[t])
+        elif mo == "sf":
+            s, r, d = env.step_sf(int(actions[t][0]))
         else:
             s, r, d = env.step_mo(int(actions[t][0]), (mo[0], mo[1]), mo[2], mo[3])
         tr = env.trace
@@ -305,7 +311,7 @@ def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_st
     store[prefix + "states_sha256"] = np.frombuffer(hashlib.sha256(bits(ref["states"]).tobytes()).digest(), np.uint8)
     store[prefix + "state_last"] = ref["states"][-1]
     store[prefix + "completion"] = np.int64(ref.get("completion_time", 0))
-    if mo is not None:
+    if mo is not None and mo != "sf":
         store[prefix + "mo"] = np.array([mo[0], mo[1], -1.0 if mo[2] is None else mo[2], -1.0 if mo[3] is None else mo[3]], np.float64)
     if full_states:
         store[prefix + "states"] = ref["states"]
@@ -325,6 +331,7 @@ def main():
     args = ap.parse_args()
     from environments.SO_FJSSP import SO_FJSSP_Environment
     from environments.MO_FJSSP_discretes import MO_FJSSP_Environment
+    from environments.SO_SFJSP import SO_SFJSP_Environment
 
     tmp = tempfile.mkdtemp(prefix="fjsp_golden_")
     report = []
@@ -334,7 +341,7 @@ def main():
         """cases: list of (label, arrays, folder_parent, folder_name)."""
         if args.only and args.only != name:
             return
-        EnvCls = SO_FJSSP_Environment if variant == "so" else MO_FJSSP_Environment
+        EnvCls = {"so": SO_FJSSP_Environment, "mo": MO_FJSSP_Environment, "sf": SO_SFJSP_Environment}[variant]
         store = {}
         suite_base = splitmix64(sum(ord(ch) for ch in name) * 7919)
         store["rng_seed_base"] = np.uint64(suite_base)
@@ -347,15 +354,15 @@ def main():
             checked_loader = False
             mo_memo = {}
             for plan in plans_store(ci) + [tuple(pl) + (False,) for pl in plans_verify(ci)]:
-                if variant == "so":
-                    (kind, seed, keep), mo = plan, None
+                if variant in ("so", "sf"):
+                    (kind, seed, keep), mo = plan, (None if variant == "so" else "sf")
                 else:
                     # (kind, seed, mo_spec, keep); mo_spec = (w0, w1, use_normalisers)
                     kind, seed, mo_spec, keep = plan
                     cn = mo_memo.get("completion") if mo_spec[2] else None
                     tn = mo_memo.get("tardiness") if mo_spec[2] else None
                     mo = (mo_spec[0], mo_spec[1], cn, tn)
-                actions = action_stream(kind, seed, Tmax, 18 if variant == "mo" else None)
+                actions = action_stream(kind, seed, Tmax, {"so": None, "mo": 18, "sf": 20}[variant])
                 # stored episode e of a suite plays with random.choice stream seed
                 # suite_base + e * 1000003 == the seed env e of a batch created with
                 # rng_seed = suite_base gets (fjsp_kernels.hip bind()); verify-only
@@ -363,7 +370,7 @@ def main():
                 rng_seed = (suite_base + ep_id * 1000003) & MASK64 if keep else splitmix64(seed * 1000003 + ci)
                 ref, env = run_reference(EnvCls, arr, parent, folder, actions, rng_seed,
                                          check_lp=(n_eps % 16 == 0), timing=timing, mo=mo)
-                if variant == "mo":      # MPPPO.py:161-164: the single-objective runs supply the normalisers
+                if variant == "mo" and mo != "sf":      # MPPPO.py:161-164: the single-objective runs supply the normalisers
                     if mo[0] == 1 and mo[2] is None:
                         mo_memo["completion"] = ref["completion_time"]
                     if mo[1] == 1 and mo[2] is None:
@@ -460,6 +467,24 @@ def main():
                       (("fixed", (4, 0)), 0, (0, 1, False), True), (("fixed", (16, 0)), 0, (0.25, 0.75, True), True)],
           lambda ci: [] if args.quick else [(("fixed", (a, 0)), 0, (0.5, 0.5, True)) for a in range(18)],
           full_state_eps={0, 2}, variant="mo")
+
+    # ---- suite 6: SO_SFJSP (the environment agents/DDQN/DDQN.py instantiates): makespan reward ------
+    sf_cases = [("benchmark/Brandimarte_Data", "Mk01"), ("DDQN", "P11"), ("DDQN", "P41"), ("MPPPO", "DDT0.5_M10_R5")]
+    s6 = fi.InstanceSet(len(sf_cases) + 2)
+    for i, (d, f) in enumerate(sf_cases):
+        s6.load_csv(i, REF + "/data/" + d, f)
+    s6g = fi.InstanceSet(2).generate_range(1000, fi.bench_10x5_params())
+    for i in range(2):
+        write_csv_folder(s6g.arrays(i), os.path.join(tmp, "sf", "S%d" % i))
+        s6.load_csv(len(sf_cases) + i, os.path.join(tmp, "sf"), "S%d" % i)
+    s6.solve_fluid()
+    cases = [(d.split("/")[-1] + "/" + f, s6.arrays(i), REF + "/data/" + d, f) for i, (d, f) in enumerate(sf_cases)]
+    cases += [("seed%d" % (1000 + i), s6.arrays(len(sf_cases) + i), os.path.join(tmp, "sf"), "S%d" % i) for i in range(2)]
+    suite("so_sfjsp", cases,
+          lambda ci: [(("random",), 81 + ci, True), (("random",), 91 + ci, True), (("fixed", (6, 0)), 0, True),
+                      (("fixed", (13, 0)), 0, True)],
+          lambda ci: [] if args.quick else [(("fixed", (a, 0)), 0) for a in range(20)],
+          full_state_eps={0}, variant="sf")
 
     report.append("LP checks vs HiGHS on the reference-built model: %d solves, max objective gap %.2e, max infeasibility %.2e"
                   % (LP_STATS["solves"], LP_STATS["max_obj_gap"], LP_STATS["max_infeas"]))

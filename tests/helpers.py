@@ -7,6 +7,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SUITES = ("mk01", "synth10x5", "multijob", "large")      # SO_FJSSP
 MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
+SF_SUITES = ("so_sfjsp",)                                    # SO_SFJSP
 
 # observation entries that pass through math.pow(x, 2) + sqrt in the reference
 # (SO_FJSSP.py:86-95): glibc pow differs from x*x by 1 ulp in ~0.08 % of arguments,
@@ -18,6 +19,9 @@ EXACT_COLS = tuple(i for i in range(20) if i not in POW_COLS)
 # (MO_FJSSP_discretes.py:59-63) and obs ct_std, cro_std, gap_std (:70-80)
 MO_POW_COLS = (4, 6, 7, 9, 11, 16, 18, 20)
 MO_EXACT_COLS = tuple(i for i in range(25) if i not in MO_POW_COLS)
+# SO_SFJSP state = [9 obs | 9 deltas]; pow()-derived: ct_std, cro_std, gap_std, gap_m_std (SO_SFJSP.py:68-81)
+SF_POW_COLS = (1, 3, 6, 8, 10, 12, 15, 17)
+SF_EXACT_COLS = tuple(i for i in range(18) if i not in SF_POW_COLS)
 POW_RTOL = 1e-12   # north_star allows 1e-5; observed differences are <= a few ulp
 POW_ATOL = 1e-12   # the v(t) - v(t-1) half cancels, so an absolute floor is needed
 
@@ -75,12 +79,14 @@ def play_oracle(arr, x, actions, rng_seed, variant=0, mo=None):
     """Play one episode on the C oracle; returns a dict shaped like the fixtures.
     mo = (w0, w1, completion, tardiness) with <= 0 standing for None selects the MO variant's step."""
     from oracle import pyoracle
-    env = pyoracle.OracleEnv(arr, x, variant, rng_seed, ddt=getattr(arr, "ddt", None) if variant else None)
+    env = pyoracle.OracleEnv(arr, x, variant, rng_seed, ddt=getattr(arr, "ddt", None) if variant == 2 else None)
     rec = {k: [] for k in ("k", "m", "job_r", "job_n", "reward", "done", "step_time", "delay", "states")}
     state0 = env.reset()
     t = 0
     while not env.done:
-        if mo is None:
+        if mo is None and variant == 1:
+            s, r, d = env.step_sf(int(actions[t][0]))
+        elif mo is None:
             s, r, d = env.step(actions[t])
         else:
             s, r, d = env.step_mo(int(actions[t][0]), (mo[0], mo[1]), mo[2] if mo[2] > 0 else None,
@@ -96,13 +102,13 @@ def play_oracle(arr, x, actions, rng_seed, variant=0, mo=None):
     return out
 
 
-def assert_state_close(got, want, what="", mo=False):
+def assert_state_close(got, want, what="", mo=False, sf=False):
     """Kernel state vs oracle/reference state: bit-exact except the pow()-derived entries."""
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
-    ex = list(MO_EXACT_COLS if mo else EXACT_COLS)
+    ex = list(SF_EXACT_COLS if sf else (MO_EXACT_COLS if mo else EXACT_COLS))
     if not np.array_equal(bits(got[..., ex]), bits(want[..., ex])):
         bad = np.argwhere(bits(got[..., ex]) != bits(want[..., ex]))[0]
         raise AssertionError("%s exact state entry differs at %s: got %r want %r"
                              % (what, bad, got[..., ex][tuple(bad)], want[..., ex][tuple(bad)]))
-    pw = list(MO_POW_COLS if mo else POW_COLS)
+    pw = list(SF_POW_COLS if sf else (MO_POW_COLS if mo else POW_COLS))
     np.testing.assert_allclose(got[..., pw], want[..., pw], rtol=POW_RTOL, atol=POW_ATOL, err_msg=what)

@@ -167,6 +167,52 @@ def test_mo_discretes_matches_reference_fixtures(torch_gpu):
             assert fin["status"][e] & ~4 == 0, tag
 
 
+def test_so_sfjsp_matches_reference_fixtures(torch_gpu):
+    """SO_SFJSP (DDQN's environment): per-step and fused kernels vs the reference traces (SO_SFJSP.py:85-222)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, VARIANT_SO_SFJSP
+    insts, eps, base = H.load_suite("so_sfjsp")
+    s = H.instance_set_from([insts[ep["inst"]] for ep in eps])
+    T = max(ep["T"] for ep in eps)
+    actions = np.zeros((T, len(eps), 2), np.uint8)
+    for e, ep in enumerate(eps):
+        actions[:ep["T"], e] = ep["actions"]
+    actions = torch.from_numpy(actions).cuda()
+    for mode in ("step", "rollout"):
+        b = EnvBatch(s, len(eps), variant=VARIANT_SO_SFJSP, rng_seed=base)
+        assert b.state_size == 18
+        st0 = b.reset().cpu().numpy()
+        for e, ep in enumerate(eps):
+            H.assert_state_close(st0[e], ep["state0"], "sf ep %d reset" % e, sf=True)
+        if mode == "step":
+            rewards = np.zeros((T, len(eps))); states = np.zeros((T, len(eps), 18))
+            for t in range(T):
+                st, r, d = b.step(actions[t])
+                rewards[t] = r.cpu().numpy(); states[t] = st.cpu().numpy()
+            trace = None
+        else:
+            trace, rw, st = b.rollout(actions)
+            trace = trace.cpu().numpy(); rewards = rw.cpu().numpy(); last = st.cpu().numpy()
+        fin = {k: v.cpu().numpy() for k, v in b.read().items()}
+        tend = b.machine_time_end().cpu().numpy()
+        for e, ep in enumerate(eps):
+            Te = ep["T"]
+            tag = "so_sfjsp %s episode %d (%s)" % (mode, e, insts[ep["inst"]].name)
+            assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(ep["reward"])), tag + " reward"
+            if trace is not None:
+                assert np.array_equal(trace[:Te, e, 0], ep["k"]) and np.array_equal(trace[:Te, e, 1], ep["m"]), tag
+                H.assert_state_close(last[e], ep["state_last"], tag, sf=True)
+            else:
+                H.assert_state_close(states[Te - 1, e], ep["state_last"], tag, sf=True)
+                if "states" in ep:
+                    H.assert_state_close(states[:Te, e], ep["states"], tag, sf=True)
+            M = insts[ep["inst"]].M
+            assert np.array_equal(tend[e, :M], ep["tend"]), tag
+            assert fin["makespan"][e] == ep["final"][0] == fin["completion_time"][e], tag
+            assert fin["delay_time_sum"][e] == ep["final"][1] and fin["step_count"][e] == Te, tag
+            assert fin["status"][e] & ~4 == 0, tag
+
+
 def test_full_size_batch_against_oracle_and_invariants(torch_gpu):
     """BASELINE config 2 at full size: 4096 generated 10x5 instances (seeds 1000+i), random policy.
 

@@ -10,7 +10,7 @@ import pytest
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES + H.SF_SUITES)
 def test_oracle_matches_reference_fixtures(built, suite):
     insts, eps, _ = H.load_suite(suite)
     assert eps, "empty fixture"
@@ -19,6 +19,9 @@ def test_oracle_matches_reference_fixtures(built, suite):
         if suite in H.MO_SUITES:
             got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=2, mo=ep["mo"])
             assert got["completion_time"] == int(ep["completion"])
+        elif suite in H.SF_SUITES:
+            got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=1)
+            assert got["completion_time"] == int(ep["completion"]) == int(ep["final"][0])
         else:
             got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"])
         tag = "%s episode %d (%s)" % (suite, e, a.name)
@@ -59,6 +62,16 @@ def test_mo_rewards_follow_the_weighting(built):
             want = -(int(ep["completion"]) / cn * w0 + int(ep["final"][1]) / tn * w1)
             assert abs(ep["reward"].sum() - want) < 1e-9 * max(1.0, abs(want)); seen.add("weighted")
     assert seen == {"tardiness", "completion", "weighted"}
+
+
+def test_sfjsp_reward_is_scaled_makespan(built):
+    """SO_SFJSP.py:216-220: rewards sum to -makespan / fluid_completed_time; tardiness counts finished jobs only."""
+    insts, eps, _ = H.load_suite("so_sfjsp")
+    for ep in eps:
+        a = insts[ep["inst"]]
+        got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=1)
+        want = -int(ep["completion"]) / got["fluid_completed_time"]
+        assert abs(ep["reward"].sum() - want) < 1e-9 * max(1.0, abs(want))
 
 
 def test_reward_telescopes_everywhere(built):
