@@ -446,6 +446,25 @@ def main():
           lambda ci: [] if args.quick else [(("fixed", (2, 0)), 0), (("fixed", (5, 1)), 0), (("random",), 131 + ci)],
           full_state_eps=set())
 
+    # ---- suite 4b: multi-order instances (order arrival re-solves the LP mid-episode, SO_FJSSP.py:218-231).
+    # Oracle-only for now: the kernels reject S > 1.
+    s4b = fi.InstanceSet(3)
+    s4b.load_csv(0, REF + "/data/HMPSAC", "DDT0.5_M20_S3")
+    s4b.generate(1, 777, fi.GenParams(R_min=3, R_max=3, J_min=2, J_max=3, M=4, p_min=20, p_max=90, N_min=2, N_max=4,
+                                      S=3, DDT=1.0, t_si_min=100.0, t_si_max=200.0))
+    s4b.generate(2, 778, fi.GenParams(R_min=4, R_max=4, J_min=3, J_max=4, M=5, p_min=40, p_max=400, N_min=2, N_max=3,
+                                      S=4, DDT=0.5, t_si_min=100.0, t_si_max=200.0))
+    s4b.solve_fluid()
+    for i in (1, 2):
+        write_csv_folder(s4b.arrays(i), os.path.join(tmp, "mo_ord", "G%d" % i))
+    cases = [("HMPSAC/DDT0.5_M20_S3", s4b.arrays(0), REF + "/data/HMPSAC", "DDT0.5_M20_S3"),
+             ("gen777", s4b.arrays(1), os.path.join(tmp, "mo_ord"), "G1"),
+             ("gen778", s4b.arrays(2), os.path.join(tmp, "mo_ord"), "G2")]
+    suite("multiorder", cases,
+          lambda ci: [(("random",), 301 + ci, True), (("fixed", (2, 0)), 0, True), (("fixed", (4, 2)), 0, True)],
+          lambda ci: [] if args.quick else [(("fixed", (0, 3)), 0), (("fixed", (3, 1)), 0), (("random",), 401 + ci)],
+          full_state_eps=set())
+
     # ---- suite 5: MO_FJSSP_discretes (the environment agents/MPPPO/MPPPO.py instantiates) ---------
     s5g = fi.InstanceSet(3).generate_range(1000, fi.bench_10x5_params())
     mo_cases = [("benchmark/Brandimarte_Data", "Mk01"), ("MPPPO", "DDT0.5_M10_R5"), ("MPPPO", "DDT1.5_M15_R5")]

@@ -8,6 +8,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SUITES = ("mk01", "synth10x5", "multijob", "large")      # SO_FJSSP
 MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
 SF_SUITES = ("so_sfjsp",)                                    # SO_SFJSP
+ORACLE_ONLY_SUITES = ("multiorder",)                          # SO_FJSSP with order arrivals: kernels reject S > 1 for now
 
 # observation entries that pass through math.pow(x, 2) + sqrt in the reference
 # (SO_FJSSP.py:86-95): glibc pow differs from x*x by 1 ulp in ~0.08 % of arguments,
@@ -79,6 +80,9 @@ def play_oracle(arr, x, actions, rng_seed, variant=0, mo=None):
     """Play one episode on the C oracle; returns a dict shaped like the fixtures.
     mo = (w0, w1, completion, tardiness) with <= 0 standing for None selects the MO variant's step."""
     from oracle import pyoracle
+    if arr.S > 1:        # order arrivals re-solve the LP on the live state (class_FJSSP.py:239): product LP as the hook
+        from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+        x = lambda Q, now: fi.fluid_lp(arr.Jr, arr.p, Q, now)[0]
     env = pyoracle.OracleEnv(arr, x, variant, rng_seed, ddt=getattr(arr, "ddt", None) if variant == 2 else None)
     rec = {k: [] for k in ("k", "m", "job_r", "job_n", "reward", "done", "step_time", "delay", "states")}
     state0 = env.reset()

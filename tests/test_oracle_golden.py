@@ -10,7 +10,7 @@ import pytest
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES + H.SF_SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES + H.SF_SUITES + H.ORACLE_ONLY_SUITES)
 def test_oracle_matches_reference_fixtures(built, suite):
     insts, eps, _ = H.load_suite(suite)
     assert eps, "empty fixture"
