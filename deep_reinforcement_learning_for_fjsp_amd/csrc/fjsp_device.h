@@ -9,8 +9,8 @@
 //     shared by every environment that plays it);
 //   * the ENV slab: one contiguous record per environment (dynamic state).
 // Inside a record every per-k array is a row of KP = 64*KC entries (one
-// coalesced load per chunk) and every (machine x op) matrix is machine-major
-// (row m = KP contiguous entries).  A wave therefore touches two address
+// coalesced load per chunk); the (machine x op) matrices are op-major (the MP
+// entries of one operation type are contiguous: the decision gathers a column).  A wave therefore touches two address
 // ranges per step -- its instance record and its own env record -- instead of
 // a dozen unrelated arrays (fewer TLB entries and DRAM pages per wave), and all
 // of its start-up loads can be issued before the first wait.
@@ -63,17 +63,18 @@ struct Layout {
     uint32_t i_tsum;    // f64[KP]  fluid_time_sum                                       [fluid_tables_kernel]
     uint32_t i_due;     // i32[JP]  job.due_date
     uint32_t i_jinfo;   // u32[JP]  k of the job's stage 0 (16) | J_r (8)
-    uint32_t i_p;       // u16[MP][KP] time_mrj_dict, 0 = ineligible
-    uint32_t i_x;       // f64[MP][KP] fluid solution (INPUT)
-    uint32_t i_rate;    // f64[MP][KP] fluid_process_rate_rj_dict                        [fluid_tables_kernel]
-    uint32_t i_arr;     // f64[MP][KP] fluid_unprocessed_rj_arrival_dict                 [fluid_tables_kernel]
+    // (machine x op) matrices are OP-MAJOR: entry (k, m) at k*MP + m, so the column of one operation type
+    // -- what machine_select gathers once k is chosen -- is MP contiguous entries
+    uint32_t i_p;       // u16[KP][MP] time_mrj_dict, 0 = ineligible
+    uint32_t i_x;       // f64[KP][MP] fluid solution (INPUT)
+    uint32_t i_col;     // f64[KP][MP][2] {fluid_unprocessed_rj_arrival_dict, fluid_process_rate_rj_dict} [fluid_tables_kernel]
     uint32_t i_ss;      // f64[8]   static state (MO variant)
     // env record: EnvScalars at 0
     uint32_t e_stride;
     uint32_t e_tend;    // i32[MP]  machine.time_end
     uint32_t e_mjob;    // i32[MP]  machine.job_object (job index)
     uint32_t e_jst;     // u32[JP]  job state words
-    uint32_t e_un;      // f64[MP][KP] machine.unprocessed_rj_dict
+    uint32_t e_un;      // f64[KP][MP] machine.unprocessed_rj_dict (op-major)
 };
 
 struct DevBatch {

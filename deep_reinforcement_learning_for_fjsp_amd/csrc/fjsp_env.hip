@@ -133,7 +133,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         L.i_kA = take(KP * 4, 4); L.i_kB = take(KP * 4, 4); L.i_elig = take(KP * 4, 4); L.i_fmask = take(KP * 4, 4);
         L.i_f4 = take(KP * 4, 4); L.i_rsum = take(KP * 8, 8); L.i_tsum = take(KP * 8, 8);
         L.i_due = take(JP * 4, 4); L.i_jinfo = take(JP * 4, 4); L.i_p = take(MP * KP * 2, 4);
-        L.i_x = take(MP * KP * 8, 8); L.i_rate = take(MP * KP * 8, 8); L.i_arr = take(MP * KP * 8, 8);
+        L.i_x = take(MP * KP * 8, 8); L.i_col = take(MP * KP * 16, 16);
         L.i_ss = take(64, 8);
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
@@ -172,8 +172,8 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
                 for (int m = 0; m < in.M; ++m) {
                     const int pv = in.p[(size_t)k * in.M + m];
                     if (pv > 0) em |= 1u << m;
-                    p[(size_t)m * KP + k] = (uint16_t)pv;
-                    x[(size_t)m * KP + k] = in.x[(size_t)k * in.M + m];
+                    p[(size_t)k * MP + m] = (uint16_t)pv;
+                    x[(size_t)k * MP + m] = in.x[(size_t)k * in.M + m];
                 }
                 elig[k] = em;
                 uint32_t f4 = 0;
@@ -341,17 +341,16 @@ int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
     const int inst = i % e->b.n_inst;
     const int K = e->inst_K[(size_t)inst], M = e->inst_M[(size_t)inst];
     const size_t KP = (size_t)e->b.KP, MP = (size_t)e->b.MP;
-    std::vector<double> rate(MP * KP), arr(MP * KP), rs(KP), ts(KP);
+    std::vector<double> col(MP * KP * 2), rs(KP), ts(KP);
     HIP_TRY(hipDeviceSynchronize());
     const unsigned char *rec = e->b.inst + (size_t)inst * e->b.L.i_stride;
-    HIP_TRY(hipMemcpy(rate.data(), rec + e->b.L.i_rate, MP * KP * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(arr.data(), rec + e->b.L.i_arr, MP * KP * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(col.data(), rec + e->b.L.i_col, MP * KP * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(rs.data(), rec + e->b.L.i_rsum, KP * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ts.data(), rec + e->b.L.i_tsum, KP * 8, hipMemcpyDeviceToHost));
     for (int k = 0; k < K; ++k) {
         for (int m = 0; m < M; ++m) {
-            if (h_rate) h_rate[(size_t)k * M + m] = rate[(size_t)m * KP + k];
-            if (h_arr) h_arr[(size_t)k * M + m] = arr[(size_t)m * KP + k];
+            if (h_rate) h_rate[(size_t)k * M + m] = col[((size_t)k * MP + m) * 2 + 1];
+            if (h_arr) h_arr[(size_t)k * M + m] = col[((size_t)k * MP + m) * 2];
         }
         if (h_rate_sum) h_rate_sum[k] = rs[(size_t)k];
         if (h_time_sum) h_time_sum[k] = ts[(size_t)k];

@@ -47,10 +47,10 @@ namespace fjsp {
 #ifdef FJSP_STAMPS
 __device__ unsigned long long fjsp_stamp_acc[16];
 #define STAMP_FIELDS unsigned long long st[10]; unsigned long long st_t0;
-#define STAMP_BEGIN(w) do { for (int _i = 0; _i < 10; ++_i) (w).st[_i] = 0; (w).st_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_BEGIN(w) do { for (int _i = 0; _i < 10; ++_i) (w).st[_i] = 0; (w).st_t0 = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP(w, slot)                                                      \
     do {                                                                    \
-        const unsigned long long _t1 = __builtin_amdgcn_s_memtime();        \
+        const unsigned long long _t1 = __builtin_amdgcn_s_memrealtime();        \
         (w).st[slot] += _t1 - (w).st_t0;                                    \
         (w).st_t0 = _t1;                                                    \
     } while (0)
@@ -157,7 +157,7 @@ template <int KC, int V>
 struct W {
     // batch constants copied out of the kernel argument (keeping a pointer to the argument struct
     // makes the compiler spill it to scratch and re-load fields through memory)
-    int KP, JP, n_obs, n_static, state_size;
+    int KP, MP, JP, n_obs, n_static, state_size;
     uint32_t e_jst, e_tend, e_mjob, e_un;
     const double *sstate;
     double fluid_completed_time;
@@ -184,10 +184,11 @@ struct W {
     int32_t *dueL;
     double *scrL;   // 16 doubles: the observation being assembled
     double *frL, *grL, *tdL;   // serial-sum operands: finish_rate[KP], gap_rate[KP], time_end[KP] (zero padded)
-    double *unp;    // unprocessed_rj matrix [MP][KP]: LDS slice (rollout) or the env record's rows (step)
+    double *unp;    // unprocessed_rj matrix [KP][MP] (op-major): LDS slice (rollout) or the env record (step)
     // rows of this instance / env record
+    // op-major matrices of the instance record: p_i[k*MP+m]; col_i[(k*MP+m)*2 + {0: arrival, 1: rate}]
     const uint16_t *p_i;
-    const double *rate_i, *arr_i;
+    const double *col_i;
     unsigned char *er;
     STAMP_FIELDS
 };
@@ -202,7 +203,7 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, boo
 template <int KC, int V>
 __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
                                          bool load_state) {
-    w.KP = b->KP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
+    w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
     w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un;
     w.env = env;
@@ -253,8 +254,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         }
     }
     w.p_i = reinterpret_cast<const uint16_t *>(ir + L.i_p);
-    w.rate_i = reinterpret_cast<const double *>(ir + L.i_rate);
-    w.arr_i = reinterpret_cast<const double *>(ir + L.i_arr);
+    w.col_i = reinterpret_cast<const double *>(ir + L.i_col);
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
     w.sstate = reinterpret_cast<const double *>(ir + L.i_ss);
     w.fluid_completed_time = w.sstate[7];
@@ -275,9 +275,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
     if (un_lds) {
         const double *src = reinterpret_cast<const double *>(er + L.e_un);
-        for (int m = 0; m < w.M; ++m)
-#pragma unroll
-            for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = src[m * KP + c * kWave + w.lane];
+        for (int i = w.lane; i < w.K * MP; i += kWave) w.unp[i] = src[i];
     }
     wave_sync();
 }
@@ -302,9 +300,7 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
     for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + w.e_jst)[n] = w.jstL[n];
     if (un_lds) {
         double *dst = reinterpret_cast<double *>(er + w.e_un);
-        for (int m = 0; m < w.M; ++m)
-#pragma unroll
-            for (int c = 0; c < KC; ++c) dst[m * KP + c * kWave + w.lane] = w.unp[m * KP + c * kWave + w.lane];
+        for (int i = w.lane; i < w.K * w.MP; i += kWave) dst[i] = w.unp[i];
     }
 }
 
@@ -460,7 +456,7 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
                 const uint32_t cand = idle & (fluid ? w.fmask[c] : w.elig[c]);
                 int best = 0x7fffffff;
                 for (int m = 0; m < w.M; ++m) {
-                    const int pv = w.p_i[m * w.KP + c * kWave + w.lane];
+                    const int pv = w.p_i[(c * kWave + w.lane) * w.MP + m];
                     if (((cand >> m) & 1u) && pv < best) best = pv;
                 }
                 tmin[c] = best;
@@ -522,9 +518,10 @@ __device__ __forceinline__ double machine_gap_ave(const W<KC, V> &w, int m) {
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int k = c * kWave + w.lane;
-        const int pm = w.p_i[m * KP + k];
+        const int o = k * w.MP + m;
+        const int pm = w.p_i[o];
         double g = 0.0;
-        if (pm > 0) g = w.unp[m * KP + k] - (w.arr_i[m * KP + k] - dt * w.rate_i[m * KP + k]);
+        if (pm > 0) g = w.unp[o] - (w.col_i[2 * o] - dt * w.col_i[2 * o + 1]);
         uint64_t em = __ballot(pm > 0);
         n += __builtin_popcountll(em);
         while (em) {
@@ -551,10 +548,16 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
     double g = 0.0, un = 0.0;
     int pm = 0;
     if (w.lane < w.M && ((sel.mask >> w.lane) & 1u)) {
-        const int o = w.lane * KP + k_sel;
+        // op-major layout: the column of k_sel is MP contiguous entries per array (a handful of cache lines)
+        const int o = k_sel * w.MP + w.lane;
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 6
+        pm = 1 + w.lane; un = 0.5; g = 0.25 * w.lane; (void)o;        // diagnostic: no column gather
+#else
         pm = w.p_i[o];
         un = w.unp[o];
-        g = un - (w.arr_i[o] - (double)w.t * w.rate_i[o]);
+        const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
+        g = un - (ar.x - (double)w.t * ar.y);
+#endif
     }
     auto visit = [&](const CandList &l, auto &&f) {
         if (l.asc) { uint32_t m = l.mask; while (m) { f((int)__builtin_ctz(m)); m &= m - 1; } }
@@ -627,7 +630,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, int k_sel, int
     const int nj = (int)(kb & 0xFFu) + 1;       // the FIFO head of (r, j) is at stage j; it moves to j + 1
     if (w.lane == 0) {
         w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);                        // :186-191
-        w.unp[m_sel * KP + k_sel] = un_sel - 1.0;                            // :198
+        w.unp[k_sel * w.MP + m_sel] = un_sel - 1.0;                          // :198
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
@@ -709,13 +712,20 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
                              (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));
     const double len = w.lane == 2 ? (double)M : (double)K;
     double frv[KC], grv[KC];
+    bool single_job = true;      // every operation type has exactly one job: the divisions below are x / 1.0 == x
+#pragma unroll
+    for (int c = 0; c < KC; ++c) single_job = single_job && __ballot((w.kA[c] >> 16) > 1u) == 0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int tot = (int)(w.kA[c] >> 16);
         const int k = c * kWave + w.lane;
         const bool valid = k < K;
-        frv[c] = valid ? (double)(tot - w.nun[c]) / (double)tot : 0.0;              // finish_rate class_FJSSP.py:74-76
-        grv[c] = valid ? ((double)w.nun[c] - fluid_q(w, c)) / (double)tot : 0.0;    // gap_rate    class_FJSSP.py:66-68
+        const double fnum = (double)(tot - w.nun[c]), gnum = (double)w.nun[c] - fluid_q(w, c);
+        if (single_job) { frv[c] = valid ? fnum : 0.0; grv[c] = valid ? gnum : 0.0; }
+        else {
+            frv[c] = valid ? fnum / (double)tot : 0.0;              // finish_rate class_FJSSP.py:74-76
+            grv[c] = valid ? gnum / (double)tot : 0.0;              // gap_rate    class_FJSSP.py:66-68
+        }
         w.frL[k] = frv[c]; w.grL[k] = grv[c];
         w.tdL[k] = (c == 0 && w.lane < M) ? (double)w.tend_m : 0.0;
     }
@@ -766,8 +776,9 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
                     int pm = 0;
                     double g = 0.0;
                     if (m < M) {
-                        pm = w.p_i[m * KP + k];
-                        if (pm > 0) g = w.unp[m * KP + k] - (w.arr_i[m * KP + k] - dt * w.rate_i[m * KP + k]);
+                        const int o = k * w.MP + m;
+                        pm = w.p_i[o];
+                        if (pm > 0) g = w.unp[o] - (w.col_i[2 * o] - dt * w.col_i[2 * o + 1]);
                     }
                     row[k] = g;
                     cnt_q[q] += __builtin_popcountll(__ballot(pm > 0));
@@ -799,17 +810,18 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         wave_sync();
         return 0;          // this subclass never calls update_parameter: delay_time_sum_unprocessed stays 0
     }
-    double dro_a = 0.0, dro_e = 0.0, drj_a = 0.0, drj_e = 0.0;
-    if (!w.done) {                                                           // :156-165
-        dro_a = (double)delay_a / (double)task_number; dro_e = (double)delay_e / (double)task_number;
-        drj_a = (double)job_a / (double)job_number; drj_e = (double)job_e / (double)job_number;
-    }
+    // the four delay ratios (:156-165): one division, lanes 0..3 carry (delay_a, delay_e) / task_number and
+    // (job_a, job_e) / job_number
+    const int num = w.lane == 0 ? delay_a : (w.lane == 1 ? delay_e : (w.lane == 2 ? job_a : job_e));
+    const int den = w.lane < 2 ? task_number : job_number;
+    const double ratio = w.done ? 0.0 : (double)num / (double)den;
+    const int o0 = V == FJSP_VARIANT_SO_FJSSP ? 1 : 0;
     if (w.lane == 0) {
-        int i = 0;
-        if (V == FJSP_VARIANT_SO_FJSSP) w.scrL[i++] = (double)M;
-        w.scrL[i++] = ct_std; w.scrL[i++] = cro_ave; w.scrL[i++] = cro_std; w.scrL[i++] = gap_ave;
-        w.scrL[i++] = gap_std; w.scrL[i++] = dro_a; w.scrL[i++] = dro_e; w.scrL[i++] = drj_a; w.scrL[i++] = drj_e;
+        if (V == FJSP_VARIANT_SO_FJSSP) w.scrL[0] = (double)M;
+        w.scrL[o0] = ct_std; w.scrL[o0 + 1] = cro_ave; w.scrL[o0 + 2] = cro_std; w.scrL[o0 + 3] = gap_ave;
+        w.scrL[o0 + 4] = gap_std;
     }
+    if (w.lane < 4) w.scrL[o0 + 5 + w.lane] = ratio;
     wave_sync();
     return tard_unproc;
 }
@@ -838,9 +850,7 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, double *state_out) {
     w.tard_done = 0; w.delay_sum = 0;
     w.tend_m = 0; w.mjob_m = -1;
     for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack((uint32_t)n, 0u);  // class_FJSSP.py:225
-    for (int m = 0; m < w.M; ++m)                                                        // :304
-#pragma unroll
-        for (int c = 0; c < KC; ++c) w.unp[m * KP + c * kWave + w.lane] = w.arr_i[m * KP + c * kWave + w.lane];
+    for (int i = w.lane; i < w.K * w.MP; i += kWave) w.unp[i] = w.col_i[2 * i];                  // :304
     wave_sync();
     wave_sync_global();       // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
     compute_params<KC, V>(w);
@@ -906,34 +916,34 @@ __device__ __forceinline__ double env_step(W<KC, V> &w, int a0, int a1, const do
 __global__ void fluid_tables_kernel(DevBatch b) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= b.n_inst * b.KP) return;
-    const int inst = idx / b.KP, k = idx % b.KP, KP = b.KP;
+    const int inst = idx / b.KP, k = idx % b.KP;
     const InstHeader h = *inst_ptr<const InstHeader>(b, inst, 0);
-    const uint16_t *p = inst_ptr<const uint16_t>(b, inst, b.L.i_p);
-    const double *x = inst_ptr<const double>(b, inst, b.L.i_x);
-    double *rate = inst_ptr<double>(b, inst, b.L.i_rate), *arr = inst_ptr<double>(b, inst, b.L.i_arr);
+    const int MP = b.MP;
+    const uint16_t *p = inst_ptr<const uint16_t>(b, inst, b.L.i_p) + (size_t)k * MP;
+    const double *x = inst_ptr<const double>(b, inst, b.L.i_x) + (size_t)k * MP;
+    double *col = inst_ptr<double>(b, inst, b.L.i_col) + (size_t)k * MP * 2;
     uint32_t fm = 0;
     double s = 0.0;
     const double q0 = (double)(inst_ptr<const uint32_t>(b, inst, b.L.i_kA)[k] >> 16);
     const bool valid = k < h.K;
     for (int m = 0; m < h.M; ++m) {
-        const int pm = p[m * KP + k];
+        const int pm = p[m];
         double r = 0.0;
         if (valid && pm > 0) {
-            const double xv = x[m * KP + k];
+            const double xv = x[m];
             r = xv * (1.0 / (double)pm);                // :164, :288-289
             if (xv != 0) fm |= 1u << m;                 // :290-292
             s = s + r;                                  // :294 (ascending m)
         }
-        rate[m * KP + k] = r;
+        col[2 * m + 1] = r;
     }
     inst_ptr<uint32_t>(b, inst, b.L.i_fmask)[k] = fm;
     inst_ptr<double>(b, inst, b.L.i_rsum)[k] = valid ? s : 0.0;
     inst_ptr<double>(b, inst, b.L.i_tsum)[k] = valid ? 1.0 / s : 0.0;       // :295
     for (int m = 0; m < h.M; ++m) {
-        const int pm = p[m * KP + k];
         double a = 0.0;
-        if (valid && pm > 0) a = (q0 * rate[m * KP + k]) / s;               // :300-302
-        arr[m * KP + k] = a;
+        if (valid && p[m] > 0) a = (q0 * col[2 * m + 1]) / s;               // :300-302
+        col[2 * m] = a;
     }
 }
 
@@ -959,7 +969,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
     if (env >= b.N) return;
-#if defined(FJSP_ABLATE) && FJSP_ABLATE >= 5
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 5
     return;                                     // diagnostic: launch overhead only
 #endif
     W<KC, V> w;
@@ -967,7 +977,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
     const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
     open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
     STAMP(w, 0);
-#if defined(FJSP_ABLATE) && FJSP_ABLATE >= 4
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 4
     store_dynamic<KC, V>(w, false);                // diagnostic: state in / state out only
     return;
 #endif
@@ -987,7 +997,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
         compute_params<KC, V>(w);
     }
     STAMP(w, 1);
-#if defined(FJSP_ABLATE) && FJSP_ABLATE >= 3
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 3
     store_dynamic<KC, V>(w, false);                // diagnostic: + compute_params
     return;
 #endif

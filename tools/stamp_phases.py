@@ -43,6 +43,6 @@ names = ["open_env (loads)", "compute_params #1 / autoreset", "task_select", "ma
          "compute_params #2", "observe", "emit_state", "outputs+store_dynamic"]
 waves = buf[15]
 tot = sum(buf[i] for i in range(9))
-print("waves", waves, "mean stamped ticks per wave", tot / waves)
+print("waves", waves, "mean stamped 100MHz ticks per wave", tot / waves)
 for i, n in enumerate(names):
     print("%-32s %8.0f ticks/wave  %5.1f %%" % (n, buf[i] / waves, 100.0 * buf[i] / tot))
