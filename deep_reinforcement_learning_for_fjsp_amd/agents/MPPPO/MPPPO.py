@@ -181,15 +181,54 @@ class PPOLearner(object):
             old_param.data.copy_(new_param.data)
 
 
+def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action):
+    """One batched episode on `env` with `learner`'s policy + one learning round (MPPPO.py:230-270).
+
+    env.step(action_tensor) must accept what encode_action(flat_action) returns.  Returns
+    (memory, losses): the RolloutBuffer used and (critic_loss, actor_loss)."""
+    from .Buffer import RolloutBuffer
+    hp = learner.hp
+    N, device = env.N, env.device
+    state64 = env.reset().clone()
+    T = max_steps
+    memory = memory_holder.get("memory")
+    if memory is None or memory.T < T or memory.N != N or memory.S != env.state_size:
+        memory = RolloutBuffer(T, N, env.state_size, device=device.index or 0)
+        memory_holder["memory"] = memory
+    memory.clear()
+    old_log_prob = torch.zeros(T, N, device=device)
+    done = torch.zeros(N, dtype=torch.uint8, device=device)
+    pair = torch.zeros(N, 2, dtype=torch.uint8, device=device)
+    t = 0
+    while t < T:
+        active = (done == 0).to(torch.uint8)
+        a, lp = learner.act(state64.float(), exploration)
+        old_log_prob[t] = lp
+        nxt, rew, dn = env.step(encode_action(a))
+        memory.add_experience(state64, pair, rew, nxt, dn, active)
+        memory.actions[t, :, 0] = a.float()          # the flat action index is what the policy is trained on
+        state64 = nxt.clone()
+        done = dn.clone()
+        t += 1
+        if t % 8 == 0 and bool((done != 0).all()):
+            break
+    n = len(memory)
+    states, actions, _, _, _ = memory.sample()
+    valid = memory.valid[:n]
+    G = memory.compute_returns(hp["discount_rate"])
+    G = normalise_returns(G, valid, hp["normalized_rewards"], hp["standardized_rewards"])
+    losses = learner.learn(states, actions[..., 0].long(), old_log_prob[:n], G, valid)
+    return memory, losses
+
+
 class PPO(Base_Agent):
-    """The agent loop of MPPPO.py:230-270 over a batch of environments.
+    """The agent loop of MPPPO.py:230-270 over a batch of SO_FJSSP environments (BASELINE config 3).
 
     `environment` is a BatchedSOFJSSP; the flat action a in [0, 30) is the rule pair
     (a // 5, a % 5) of SO_FJSSP's [6, 5] action space."""
 
     def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None):
         super().__init__()
-        from .Buffer import RolloutBuffer
         self.environment = environment
         self.device = environment.device
         self.state_size = environment.state_size
@@ -198,47 +237,130 @@ class PPO(Base_Agent):
                                   device=self.device, seed=seed, hyper=hyper)
         self.hyper_parameters = self.learner.hp
         self.max_steps = max_steps
-        self.memory = None
-        self._RolloutBuffer = RolloutBuffer
+        self._holder = {}
         self.global_step_number = 0
+        self._pair = torch.zeros(environment.N, 2, dtype=torch.uint8, device=self.device)
+
+    @property
+    def memory(self):
+        return self._holder.get("memory")
+
+    def _encode(self, a):
+        n1 = self.environment.actions_size[1]
+        self._pair[:, 0] = (a // n1).to(torch.uint8)
+        self._pair[:, 1] = (a % n1).to(torch.uint8)
+        return self._pair
 
     def run_one_policy_network(self, exploration=None):
-        """One batched episode + one learning round. Returns (mean delay_time_sum, mean makespan)."""
-        env, N = self.environment, self.environment.N
+        """One batched episode + one learning round. Returns (mean delay_time_sum, mean makespan, losses)."""
         hp = self.hyper_parameters
         if exploration is None:                                                         # :240-241
             exploration = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])
-        state64 = env.reset().clone()
-        T = self.max_steps or 64
-        if self.memory is None or self.memory.T < T:
-            self.memory = self._RolloutBuffer(T, N, self.state_size, device=self.device.index or 0)
-        self.memory.clear()
-        old_log_prob = torch.zeros(T, N, device=self.device)
-        done = torch.zeros(N, dtype=torch.uint8, device=self.device)
-        act_pair = torch.zeros(N, 2, dtype=torch.uint8, device=self.device)
-        t = 0
-        while t < T:
-            active = (done == 0).to(torch.uint8)
-            a, lp = self.learner.act(state64.float(), exploration)
-            act_pair[:, 0] = (a // env.actions_size[1]).to(torch.uint8)
-            act_pair[:, 1] = (a % env.actions_size[1]).to(torch.uint8)
-            old_log_prob[t] = lp
-            nxt, rew, dn = env.step(act_pair)
-            # the flat action index is what the policy is trained on
-            self.memory.add_experience(state64, act_pair, rew, nxt, dn, active)
-            self.memory.actions[t, :, 0] = a.float()
-            state64 = nxt.clone()
-            done = dn.clone()
-            t += 1
-            self.global_step_number += int(N)
-            if t % 8 == 0 and bool((done != 0).all()):
-                break
-        n = len(self.memory)
-        states, actions, rewards, _, _ = self.memory.sample()
-        valid = self.memory.valid[:n]
-        G = self.memory.compute_returns(hp["discount_rate"])
-        G = normalise_returns(G, valid, hp["normalized_rewards"], hp["standardized_rewards"])
-        losses = self.learner.learn(states, actions[..., 0].long(), old_log_prob[:n], G, valid)
+        memory, losses = collect_and_learn(self.environment, self.learner, self._holder, exploration,
+                                           self.max_steps or 64, self._encode)
+        self.global_step_number += int(memory.valid[:len(memory)].sum().item())
         self.episode_number += 1
-        r = env.read()
+        r = self.environment.read()
         return float(r["delay_time_sum"].double().mean()), float(r["makespan"].double().mean()), losses
+
+
+class MPPPO(Base_Agent):
+    """Multi-policy PPO of agents/MPPPO/MPPPO.py:70-212 on batches of MO_FJSSP_discretes environments.
+
+    actor_number policies share the environment; policy p is trained on the weight vector
+    (1 - p/(n-1), p/(n-1)) (:111).  One epoch (:159-164): the completion policy (p = 0) and the tardiness
+    policy (p = n-1) run first on the training batch and their per-environment objective values
+    normalise the rewards of the weighted policies; every `evolve_every` epochs the policies are pulled
+    towards the best policy for their weight vector (:192-205).
+
+    Two defects of the shipped script are fixed, not replicated: completion_min / tardiness_min stay +inf
+    there (:134-135, never updated), which zeroes every score of the evolution step; here they track the
+    best test objectives seen.  `make_train_env()` is called once per epoch like
+    generated_new_environment() (:149-154,160)."""
+
+    def __init__(self, make_train_env, test_env, actor_number=5, hidden_size=200, hidden_layer=5, critic_layer=3,
+                 seed=0, hyper=None, max_steps=64, evolve_every=30):
+        super().__init__()
+        self.make_train_env, self.test_env = make_train_env, test_env
+        self.device = test_env.device
+        self.actor_number = actor_number
+        self.policy_tuple = tuple(range(actor_number))
+        self.policy_completion, self.policy_tardiness = self.policy_tuple[0], self.policy_tuple[-1]
+        self.policy_weight_tuple = self.policy_tuple[1:-1]
+        self.weight_vector_dict = {p: (1 - 1 / (actor_number - 1) * p, 1 / (actor_number - 1) * p)
+                                   for p in self.policy_tuple}                            # :111
+        self.learners = {p: PPOLearner(25, 18, hidden_size, hidden_layer, critic_layer, device=self.device,
+                                       seed=seed + p, hyper=hyper) for p in self.policy_tuple}
+        self.hyper_parameters = self.learners[0].hp
+        self.max_steps, self.evolve_every = max_steps, evolve_every
+        self.completion_min = float("inf")
+        self.tardiness_min = float("inf")
+        self._holder = {}
+
+    def run_one_policy_network(self, environment, policy_number, completion=None, tardiness=None):
+        """:230-270 for every environment of the batch. Returns per-env (delay_time_sum, completion_time)."""
+        hp = self.hyper_parameters
+        eps = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])      # :240
+        environment.set_objective(self.weight_vector_dict[policy_number], completion, tardiness)
+        collect_and_learn(environment, self.learners[policy_number], self._holder, eps, self.max_steps, lambda a: a)
+        r = environment.read()
+        return r["delay_time_sum"].double(), r["completion_time"].double()
+
+    @torch.no_grad()
+    def run_one_epoch(self, environment, policy_number, completion=None, tardiness=None):
+        """:214-228: evaluation episode (epsilon 0, no learning). Returns mean (delay_time_sum, completion_time)."""
+        environment.set_objective(self.weight_vector_dict[policy_number], completion, tardiness)
+        state = environment.reset()
+        done = torch.zeros(environment.N, dtype=torch.uint8, device=self.device)
+        for t in range(self.max_steps):
+            a, _ = self.learners[policy_number].act(state.float(), 0.0)
+            state, _, done = environment.step(a)
+            if t % 8 == 7 and bool((done != 0).all()):
+                break
+        r = environment.read()
+        return float(r["delay_time_sum"].double().mean()), float(r["completion_time"].double().mean())
+
+    def run_n_episodes(self, n):
+        """:156-190. Returns the list of per-epoch {policy: (completion, tardiness)} test objectives."""
+        history = []
+        for _ in range(n):
+            env = self.make_train_env()
+            _, completion = self.run_one_policy_network(env, self.policy_completion)
+            tardiness, _ = self.run_one_policy_network(env, self.policy_tardiness)
+            completion, tardiness = completion.clamp(min=1.0), tardiness.clamp(min=1.0)
+            for p in self.policy_weight_tuple:
+                self.run_one_policy_network(env, p, completion=completion, tardiness=tardiness)
+            objs = {}
+            t_c, c = self.run_one_epoch(self.test_env, self.policy_completion)
+            objs[self.policy_completion] = (c, t_c)
+            t, c_t = self.run_one_epoch(self.test_env, self.policy_tardiness)
+            objs[self.policy_tardiness] = (c_t, t)
+            for p in self.policy_weight_tuple:
+                t_p, c_p = self.run_one_epoch(self.test_env, p, completion=max(c, 1.0), tardiness=max(t, 1.0))
+                objs[p] = (c_p, t_p)
+            self.completion_min = min(self.completion_min, min(v[0] for v in objs.values()))
+            self.tardiness_min = min(self.tardiness_min, min(v[1] for v in objs.values()))
+            history.append(objs)
+            self.episode_number += 1
+            if self.episode_number % self.evolve_every == 0:
+                self.multi_policy_update(objs)
+        return history
+
+    def multi_policy_update(self, policy_objectives):
+        """:192-205: every policy moves (soft update, tau) towards the policy whose test objectives score
+        best under ITS weight vector."""
+        import copy
+        actors = {p: copy.deepcopy(self.learners[p].actor_new) for p in self.policy_tuple}
+        critics = {p: copy.deepcopy(self.learners[p].critic) for p in self.policy_tuple}
+        tau = self.hyper_parameters["tau"]
+        cmin, tmin = max(self.completion_min, 1e-9), max(self.tardiness_min, 1e-9)
+        chosen = {}
+        for policy in self.policy_tuple:
+            w = self.weight_vector_dict[policy]
+            scores = [w[0] * (policy_objectives[q][0] / cmin) + w[1] * (policy_objectives[q][1] / tmin)
+                      for q in self.policy_tuple]
+            best = scores.index(min(scores))
+            chosen[policy] = best
+            self.soft_update_of_target_network(actors[best], self.learners[policy].actor_new, tau)
+            self.soft_update_of_target_network(critics[best], self.learners[policy].critic, tau)
+        return chosen

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3 / 4: batched PPO (actor/critic 2x128) on 4096 SO_FJSSP 10x5 environments per GPU,
+HIP environment + C-ABI rollout buffer + PyTorch-ROCm update; with N GPUs the env ids are sharded and the
+flat gradient bucket is all-reduced over RCCL once per optimiser step.
+
+    python examples/train_ppo.py --rounds 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_ppo.py --rounds 5
+
+Prints one JSON line per rank-0 run: env-steps/s of the whole loop (policy inference + env + learning)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    from deep_reinforcement_learning_for_fjsp_amd import distributed as fd, instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedSOFJSSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import PPO
+
+    fd.init_from_env()
+    rank, world = fd.rank(), fd.world_size()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    N = args.envs_per_gpu
+    insts = fi.InstanceSet(N).generate_range(1000 + rank * N, fi.bench_10x5_params()).solve_fluid()
+    env = BatchedSOFJSSP(insts, device=local, rng_seed=7 + rank * N)
+    torch.manual_seed(1234 + rank)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56)
+    agent.run_one_policy_network()          # warm-up round (allocations, kernel caches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps0 = agent.global_step_number
+    out = None
+    for _ in range(args.rounds):
+        out = agent.run_one_policy_network()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        steps = (agent.global_step_number - steps0) * world
+        print(json.dumps({"workload": "PPO 2x128 on %d SO_FJSSP 10x5 envs per GPU" % N, "n_gpus": world,
+                          "rounds": args.rounds, "env_steps_per_s": steps / dt, "s_per_round": dt / args.rounds,
+                          "mean_tardiness": out[0], "mean_makespan": out[1], "losses": out[2]}))
+    if fd.is_distributed():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

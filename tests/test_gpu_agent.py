@@ -75,3 +75,36 @@ def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu):
         tot = (agent.memory.rewards[:n].double() * valid.double()).sum(0)
         assert torch.equal(-tot.long(), r["delay_time_sum"])
     assert agent.episode_number == 3 and agent.global_step_number > 0
+
+
+def test_multi_policy_ppo_on_mo_discretes(torch_gpu):
+    """agents/MPPPO/MPPPO.py end to end on the environment it instantiates (MO_FJSSP_discretes):
+    5 policies, completion / tardiness normalisers from the single-objective runs, evolution step."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedMOFJSSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import MPPPO
+    N = 128
+    test_set = fi.InstanceSet(16).generate_range(5000, fi.bench_10x5_params()).solve_fluid()
+    test_env = BatchedMOFJSSP(test_set, rng_seed=1)
+    epoch = [0]
+
+    def make_train_env():       # a fresh random batch per epoch, like generated_new_environment() (MPPPO.py:149-154)
+        epoch[0] += 1
+        s = fi.InstanceSet(N).generate_range(10000 * epoch[0], fi.bench_10x5_params()).solve_fluid()
+        return BatchedMOFJSSP(s, rng_seed=epoch[0])
+
+    torch.manual_seed(0)
+    agent = MPPPO(make_train_env, test_env, actor_number=5, hidden_size=64, hidden_layer=2, critic_layer=2,
+                  max_steps=56, evolve_every=1)
+    assert agent.weight_vector_dict[0] == (1.0, 0.0) and agent.weight_vector_dict[4] == (0.0, 1.0)
+    before = [p.detach().clone() for p in agent.learners[2].actor_new.parameters()]
+    hist = agent.run_n_episodes(2)
+    assert len(hist) == 2 and set(hist[0]) == set(range(5))
+    for objs in hist:
+        for c, t in objs.values():
+            assert np.isfinite(c) and np.isfinite(t) and c > 0
+    assert np.isfinite(agent.completion_min) and np.isfinite(agent.tardiness_min)
+    assert any(not torch.equal(b, p) for b, p in zip(before, agent.learners[2].actor_new.parameters()))
+    chosen = agent.multi_policy_update(hist[-1])
+    assert set(chosen) == set(range(5)) and all(0 <= v < 5 for v in chosen.values())
