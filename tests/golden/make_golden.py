@@ -446,6 +446,26 @@ def main():
           lambda ci: [] if args.quick else [(("fixed", (2, 0)), 0), (("fixed", (5, 1)), 0), (("random",), 131 + ci)],
           full_state_eps=set())
 
+    # ---- suite 4a: degenerate sizes (one kind / one operation / one machine / several jobs of one kind) ----
+    edge_prm = [dict(R_min=1, R_max=1, J_min=1, J_max=1, M=1, N_min=1, N_max=1),
+                dict(R_min=1, R_max=1, J_min=1, J_max=1, M=2, N_min=3, N_max=3),
+                dict(R_min=1, R_max=1, J_min=3, J_max=3, M=1, N_min=2, N_max=2),
+                dict(R_min=2, R_max=2, J_min=1, J_max=2, M=2, N_min=1, N_max=2),
+                dict(R_min=3, R_max=3, J_min=2, J_max=2, M=8, N_min=1, N_max=1),
+                dict(R_min=2, R_max=2, J_min=5, J_max=5, M=3, N_min=4, N_max=5)]
+    s4a = fi.InstanceSet(len(edge_prm))
+    cases = []
+    for i, kw in enumerate(edge_prm):
+        s4a.generate(i, 9000 + i, fi.GenParams(p_min=1, p_max=9, S=1, DDT=1.0, t_si_min=100.0, t_si_max=200.0, **kw))
+    s4a.solve_fluid()
+    for i in range(len(edge_prm)):
+        write_csv_folder(s4a.arrays(i), os.path.join(tmp, "edge", "E%d" % i))
+        cases.append(("edge%d" % i, s4a.arrays(i), os.path.join(tmp, "edge"), "E%d" % i))
+    suite("edge", cases,
+          lambda ci: [(kp, 0, True) for kp in ALL_PAIRS[ci % 3::3]] + [(("random",), 7 + ci, True)],
+          lambda ci: [(kp, 0) for kp in ALL_PAIRS],
+          full_state_eps=set(range(0, 66, 5)))
+
     # ---- suite 4b: multi-order instances (order arrival re-solves the LP mid-episode, SO_FJSSP.py:218-231).
     # Oracle-only for now: the kernels reject S > 1.
     s4b = fi.InstanceSet(3)

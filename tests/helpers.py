@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUITES = ("mk01", "synth10x5", "multijob", "large")      # SO_FJSSP
+SUITES = ("mk01", "synth10x5", "multijob", "large", "edge")      # SO_FJSSP
 MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
 SF_SUITES = ("so_sfjsp",)                                    # SO_SFJSP
 ORACLE_ONLY_SUITES = ("multiorder",)                          # SO_FJSSP with order arrivals: kernels reject S > 1 for now

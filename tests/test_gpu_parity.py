@@ -284,6 +284,42 @@ def test_full_size_batch_against_oracle_and_invariants(torch_gpu):
     assert np.array_equal(H.bits(r.cpu().numpy()[idx]), H.bits(ep1[0][1].cpu().numpy()[idx]))
 
 
+def test_instance_sharing_and_masked_reset(torch_gpu):
+    """env e plays instance e % n_inst; reset(mask) restarts only the masked envs (the others keep going)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+    s = fi.InstanceSet(3).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
+    N = 10                                          # not a multiple of the 4 envs per workgroup
+    b = EnvBatch(s, N, rng_seed=0)
+    act = torch.tensor([[2, 0]] * N, dtype=torch.uint8, device="cuda")
+    first = b.reset().clone()
+    for e in range(N):
+        assert torch.equal(first[e], first[e % 3])
+    hist = []
+    for t in range(12):
+        st, r, d = b.step(act)
+        hist.append((st.clone(), r.clone()))
+        for e in range(N):                          # deterministic rules: envs sharing an instance move in lock-step
+            assert torch.equal(st[e], st[e % 3]) and r[e] == r[e % 3]
+    mask = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    mask[[1, 4, 9]] = 1
+    before = b.state.clone()
+    st = b.reset(mask)
+    for e in range(N):
+        if mask[e]:
+            assert torch.equal(st[e], first[e])
+        else:
+            assert torch.equal(st[e], before[e])
+    for t in range(12):
+        st, r, d = b.step(act)
+        for e in (1, 4, 9):                         # the restarted envs replay their first episode
+            assert torch.equal(st[e], hist[t][0][e]) and r[e] == hist[t][1][e]
+    rd = b.read()
+    assert rd["step_count"].cpu().tolist() == [12 if m else 24 for m in mask.cpu().tolist()]
+    assert int(rd["status"].abs().sum()) == 0
+
+
 def test_error_behaviour(torch_gpu):
     """MyError on undefined rules, error on stepping a finished episode, picklable env."""
     import pickle
