@@ -43,7 +43,9 @@ struct EnvScalars {
     int32_t completion_last;
     int64_t tard_done;       // delay_time_sum_processed                (SO_FJSSP.py:45)
     int64_t delay_sum;       // delay_time_sum == delay_time_sum_last after a step (:44,263)
-    int64_t reserved;
+    int32_t t_arr;           // self.order_arrive_time                  (:19)
+    int16_t next_order;      // index of the first order not yet arrived (order_object_list, :53-56)
+    int16_t pending;         // 1 = the event loop stopped at an order arrival and waits for its fluid LP
     double obs_prev[10];     // observation_state v(t)                  (:21)
 };
 static_assert(sizeof(EnvScalars) == 18 * 8, "EnvScalars must be 18 words");
@@ -68,17 +70,29 @@ struct Layout {
     uint32_t i_p;       // u16[KP][MP] time_mrj_dict, 0 = ineligible
     uint32_t i_x;       // f64[KP][MP] fluid solution (INPUT)
     uint32_t i_col;     // f64[KP][MP][2] {fluid_unprocessed_rj_arrival_dict, fluid_process_rate_rj_dict} [fluid_tables_kernel]
-    uint32_t i_ss;      // f64[8]   static state (MO variant)
+    uint32_t i_ss;      // f64[8]   static state (MO variant); [7] = fluid_completed_time of the reset-time LP
+    uint32_t i_oarr;    // i32[SP]  time_arrive_s_dict                                   (multi-order batches)
+    uint32_t i_ocnt;    // u16[SP][RP] count_sr_dict                                     (multi-order batches)
     // env record: EnvScalars at 0
     uint32_t e_stride;
     uint32_t e_tend;    // i32[MP]  machine.time_end
     uint32_t e_mjob;    // i32[MP]  machine.job_object (job index)
     uint32_t e_jst;     // u32[JP]  job state words
     uint32_t e_un;      // f64[KP][MP] machine.unprocessed_rj_dict (op-major)
+    // multi-order batches only: the fluid tables change at every order arrival, so they live per environment
+    uint32_t e_q0;      // u32[KP]  fluid_unprocessed_number_start
+    uint32_t e_fmask;   // u32[KP]
+    uint32_t e_rsum;    // f64[KP]
+    uint32_t e_tsum;    // f64[KP]
+    uint32_t e_col;     // f64[KP][MP][2]
+    uint32_t e_xin;     // f64[KP][MP] fluid solution of the pending LP, written by the host service
+    uint32_t e_lpq;     // u16[2][KP] LP inputs of the pending arrival: Q[k], n_now[k]; then i16[2] stashed (k, m) of the step
 };
 
 struct DevBatch {
     int32_t N, n_inst, KC, KP, MP, JP, variant, n_obs, n_static, state_size;
+    int32_t mord, SP, RP;    // multi-order batch (S > 1): order / kind paddings of i_oarr, i_ocnt
+    uint32_t *pending_count; // number of envs that stopped at an order arrival in the last launch (multi-order)
     uint64_t rng_seed;
     unsigned char *inst;     // [n_inst] instance records
     unsigned char *envs;     // [N] env records
@@ -102,6 +116,9 @@ int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int
 size_t rollout_lds_bytes(const DevBatch &b);
 int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st);
+// multi-order: resume the envs whose pending LP has been solved (x in e_xin)
+int launch_arrival(const DevBatch &b, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
+                   hipStream_t st);
 int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
                 int32_t *step_count, uint8_t *done, uint32_t *status, hipStream_t st);
 

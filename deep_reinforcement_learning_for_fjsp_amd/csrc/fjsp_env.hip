@@ -23,6 +23,10 @@ struct fjsp_env {
     int64_t step_bytes = 0;
     // scratch for the non-fused rollout fallback
     uint8_t *d_done_scratch = nullptr;
+    // multi-order service (host LP at order arrivals)
+    const fjsp_instances *src = nullptr;
+    int first = 0;
+    std::vector<uint32_t> h_pending;
 };
 
 namespace {
@@ -82,20 +86,23 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     if (variant != FJSP_VARIANT_SO_FJSSP && variant != FJSP_VARIANT_SO_SFJSP && variant != FJSP_VARIANT_MO_FJSSP_DISCRETES) {
         set_error("fjsp_env_create: unknown variant"); return FJSP_E_ARG;
     }
-    int Kmax = 0, Mmax = 0, Jmax = 0;
+    int Kmax = 0, Mmax = 0, Jmax = 0, Smax = 1, Rmax = 0;
     for (int i = 0; i < n_inst; ++i) {
         const Instance &in = s->v[(size_t)first + i];
         if (!in.valid) { set_error("fjsp_env_create: instance not populated"); return FJSP_E_STATE; }
         if (!in.has_x) { set_error("fjsp_env_create: fluid solution missing (call fjsp_instances_solve_fluid)"); return FJSP_E_STATE; }
-        if (in.S != 1) { set_error("multi-order instances (order arrival re-solves the LP mid-episode) are not supported by the kernels yet"); return FJSP_E_UNSUPPORTED; }
+        if (in.S != 1 && variant != FJSP_VARIANT_SO_FJSSP) { set_error("only SO_FJSSP handles order arrivals (the subclasses are single-order, SO_SFJSP.py:20 / MO_FJSSP_discretes.py:21)"); return FJSP_E_UNSUPPORTED; }
+        if (in.S > 64) { set_error("more than 64 orders"); return FJSP_E_UNSUPPORTED; }
+        Smax = std::max(Smax, in.S); Rmax = std::max(Rmax, in.R);
         if (in.K > kWave * kMaxKC) { set_error("more than 256 operation types"); return FJSP_E_UNSUPPORTED; }
         if (in.M > kMaxM) { set_error("more than 32 machines"); return FJSP_E_UNSUPPORTED; }
-        const int nj = in.jobs_of_order(0);
+        const int nj = in.jobs_total();
         if (nj > 65535) { set_error("more than 65535 jobs"); return FJSP_E_UNSUPPORTED; }
         {
             long ntasks = 0;
-            for (int r = 0; r < in.R; ++r) ntasks += (long)in.count[r] * in.Jr[r];
-            if (ntasks > 65535) { set_error("more than 65535 operations in one order"); return FJSP_E_UNSUPPORTED; }
+            for (int so = 0; so < in.S; ++so)
+                for (int r = 0; r < in.R; ++r) ntasks += (long)in.count[(size_t)so * in.R + r] * in.Jr[r];
+            if (ntasks > 65535) { set_error("more than 65535 operations"); return FJSP_E_UNSUPPORTED; }
         }
         for (int r = 0; r < in.R; ++r)
             if (in.Jr[r] > 255) { set_error("more than 255 operations in a kind"); return FJSP_E_UNSUPPORTED; }
@@ -124,6 +131,8 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.n_static = variant == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 7 : 0;
     b.state_size = b.n_static + 2 * b.n_obs;
     b.rng_seed = rng_seed;
+    b.mord = Smax > 1 ? 1 : 0; b.SP = Smax; b.RP = Rmax;
+    e->src = s; e->first = first;
     const size_t KP = (size_t)b.KP, MP = (size_t)b.MP, JP = (size_t)b.JP, NI = (size_t)n_inst, N = (size_t)n_envs;
     // ---- record layouts (fjsp_device.h)
     Layout &L = b.L;
@@ -135,9 +144,14 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         L.i_due = take(JP * 4, 4); L.i_jinfo = take(JP * 4, 4); L.i_p = take(MP * KP * 2, 4);
         L.i_x = take(MP * KP * 8, 8); L.i_col = take(MP * KP * 16, 16);
         L.i_ss = take(64, 8);
+        L.i_oarr = take((size_t)Smax * 4, 4); L.i_ocnt = take((size_t)Smax * Rmax * 2, 4);
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(MP * KP * 8, 8);
+        if (b.mord) {
+            L.e_q0 = take(KP * 4, 4); L.e_fmask = take(KP * 4, 4); L.e_rsum = take(KP * 8, 8); L.e_tsum = take(KP * 8, 8);
+            L.e_col = take(MP * KP * 16, 16); L.e_xin = take(MP * KP * 8, 8); L.e_lpq = take(KP * 4 + 8, 4);
+        }
         L.e_stride = (uint32_t)((o + 255) / 256 * 256);
     }
     std::vector<unsigned char> islab(NI * L.i_stride, 0);
@@ -145,8 +159,16 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     double bytes_acc = 0.0;
     for (size_t i = 0; i < NI; ++i) {
         const Instance &in = s->v[(size_t)first + i];
-        const int nj = in.jobs_of_order(0);
-        *reinterpret_cast<InstHeader *>(ip(i, 0)) = InstHeader{in.K, in.M, in.R, nj};
+        const int nj = in.jobs_total();
+        *reinterpret_cast<InstHeader *>(ip(i, 0)) = InstHeader{in.K, in.M, in.R | (b.mord ? in.S << 16 : 0), nj};
+        {
+            int32_t *oarr = reinterpret_cast<int32_t *>(ip(i, L.i_oarr));
+            uint16_t *ocnt = reinterpret_cast<uint16_t *>(ip(i, L.i_ocnt));
+            for (int so = 0; so < in.S; ++so) {
+                oarr[so] = in.arrive[so];
+                for (int r = 0; r < in.R; ++r) ocnt[(size_t)so * Rmax + r] = (uint16_t)in.count[(size_t)so * in.R + r];
+            }
+        }
         e->inst_K.push_back(in.K); e->inst_M.push_back(in.M);
         uint32_t *kA = reinterpret_cast<uint32_t *>(ip(i, L.i_kA)), *kB = reinterpret_cast<uint32_t *>(ip(i, L.i_kB));
         uint32_t *elig = reinterpret_cast<uint32_t *>(ip(i, L.i_elig)), *first4 = reinterpret_cast<uint32_t *>(ip(i, L.i_f4));
@@ -156,12 +178,18 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         double *x = reinterpret_cast<double *>(ip(i, L.i_x));
         int jbeg = 0;
         for (int r = 0; r < in.R; ++r) {
-            const int cnt = in.count[r];
-            // class_FJSSP.py:214-218: r_due = round(delivery * J_r / N_r); due(n) = round(r_due * n / N_r)
-            const long r_due = py_round((double)((long)in.delivery[0] * in.Jr[r]) / (double)cnt);
-            for (int n = 0; n < cnt; ++n) {
-                due[jbeg + n] = (int32_t)py_round((double)(r_due * n) / (double)cnt);
-                jinfo[jbeg + n] = (uint32_t)in.koff[r] | ((uint32_t)in.Jr[r] << 16);
+            // jobs of kind r over ALL orders, numbered in arrival order (Kind.number_start, class_FJSSP.py:212-217);
+            // class_FJSSP.py:214-218: r_due = round(delivery_s * J_r / N_sr); due(n) = round(r_due * n / N_sr) with
+            // the ABSOLUTE job number n
+            int cnt = 0;
+            for (int so = 0; so < in.S; ++so) {
+                const int c_s = in.count[(size_t)so * in.R + r];
+                const long r_due = py_round((double)((long)in.delivery[so] * in.Jr[r]) / (double)c_s);
+                for (int n = cnt; n < cnt + c_s; ++n) {
+                    due[jbeg + n] = (int32_t)py_round((double)(r_due * n) / (double)c_s);
+                    jinfo[jbeg + n] = (uint32_t)in.koff[r] | ((uint32_t)in.Jr[r] << 16);
+                }
+                cnt += c_s;
             }
             for (int j = 0; j < in.Jr[r]; ++j) {
                 const int k = in.koff[r] + j;
@@ -232,6 +260,12 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         if (!hip_ok(hipMalloc(&pd, N + 16), "hipMalloc scratch")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
         e->allocs.push_back(pd);
         e->d_done_scratch = reinterpret_cast<uint8_t *>(pd);
+        if (b.mord) {
+            void *pp = nullptr;
+            if (!hip_ok(hipMalloc(&pp, (N + 1) * 4), "hipMalloc pending list") || !hip_ok(hipMemset(pp, 0, (N + 1) * 4), "hipMemset")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
+            e->allocs.push_back(pp);
+            b.pending_count = reinterpret_cast<uint32_t *>(pp);
+        }
         b.inst = reinterpret_cast<unsigned char *>(pi);
         b.envs = reinterpret_cast<unsigned char *>(pe);
         // every env starts done so that step() before reset() is flagged, like the
@@ -266,6 +300,43 @@ int fjsp_env_state_size(const fjsp_env *e) { return e ? e->b.state_size : 0; }
 int fjsp_env_device(const fjsp_env *e) { return e ? e->device : -1; }
 int64_t fjsp_env_step_bytes(const fjsp_env *e) { return e ? e->step_bytes : 0; }
 
+namespace {
+// Multi-order batches: after a step launch, solve the fluid LP of every env that stopped at an order
+// arrival (class_FJSSP.py:239 on the live state) with the host simplex and let arrival_kernel finish
+// those steps.  Synchronises the stream: order arrivals make step() blocking for such batches.
+int service_arrivals(fjsp_env *e, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace, hipStream_t st) {
+    const DevBatch &b = e->b;
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, b.pending_count, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n == 0) return FJSP_OK;
+    e->h_pending.resize(n);
+    HIP_TRY(hipMemcpy(e->h_pending.data(), b.pending_count + 1, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const size_t KP = (size_t)b.KP, MP = (size_t)b.MP;
+    std::vector<uint16_t> lpq(2 * KP);
+    std::vector<double> xin(KP * MP), xk;
+    std::vector<int> Q, now;
+    for (uint32_t q = 0; q < n; ++q) {
+        const int env = (int)e->h_pending[q];
+        const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
+        unsigned char *rec = b.envs + (size_t)env * b.L.e_stride;
+        HIP_TRY(hipMemcpy(lpq.data(), rec + b.L.e_lpq, 2 * KP * 2, hipMemcpyDeviceToHost));
+        Q.assign(in.K, 0); now.assign(in.K, 0);
+        for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
+        xk.assign((size_t)in.K * in.M, 0.0);
+        double obj = 0.0;
+        if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) return FJSP_E_LP;
+        std::fill(xin.begin(), xin.end(), 0.0);
+        for (int k = 0; k < in.K; ++k)
+            for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
+        HIP_TRY(hipMemcpy(rec + b.L.e_xin, xin.data(), KP * MP * 8, hipMemcpyHostToDevice));
+    }
+    if (launch_arrival(b, (int)n, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
+    HIP_TRY(hipMemsetAsync(b.pending_count, 0, 4, st));
+    return FJSP_OK;
+}
+}  // namespace
+
 int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *stream) {
     if (!e) { set_error("fjsp_env_reset: null env"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
@@ -280,6 +351,7 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
     if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
     }
+    if (e->b.mord) return service_arrivals(e, d_state, d_reward, d_done, nullptr, (hipStream_t)stream);
     return FJSP_OK;
 }
 
@@ -288,7 +360,7 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, 
     if (!e || !d_actions || T <= 0) { set_error("fjsp_env_rollout: bad arguments"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
     hipStream_t st = (hipStream_t)stream;
-    if (rollout_lds_bytes(e->b) <= 64 * 1024) {
+    if (!e->b.mord && rollout_lds_bytes(e->b) <= 64 * 1024) {
         if (launch_rollout(e->b, d_actions, d_mo, T, d_trace_km, d_reward, d_state_last, st) != 0) {
             set_error("rollout_kernel launch failed"); return FJSP_E_HIP;
         }
@@ -300,6 +372,11 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, 
         if (launch_step(e->b, d_actions + (size_t)s2 * N * 2, d_mo, 2, d_state_last, d_reward ? d_reward + (size_t)s2 * N : nullptr,
                         e->d_done_scratch, d_trace_km ? d_trace_km + (size_t)s2 * N * 2 : nullptr, st) != 0) {
             set_error("step_kernel launch failed"); return FJSP_E_HIP;
+        }
+        if (e->b.mord) {
+            const int rc = service_arrivals(e, d_state_last, d_reward ? d_reward + (size_t)s2 * N : nullptr, e->d_done_scratch,
+                                            d_trace_km ? d_trace_km + (size_t)s2 * N * 2 : nullptr, st);
+            if (rc != FJSP_OK) return rc;
         }
     }
     return FJSP_OK;

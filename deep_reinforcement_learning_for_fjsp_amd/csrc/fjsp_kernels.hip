@@ -41,6 +41,14 @@
 
 namespace fjsp {
 
+// Internal variant id: SO_FJSSP whose instance has more than one order (order arrivals re-solve the fluid
+// LP mid-episode, SO_FJSSP.py:218-231).  Its fluid tables live in the env record and its step can stop at
+// an arrival and be finished by arrival_kernel once the host has solved the LP.
+constexpr int kMord = 3;
+template <int V>
+constexpr bool is_so_v = (V == FJSP_VARIANT_SO_FJSSP || V == kMord);
+constexpr uint32_t kAbsent = 0xFFu;      // next_stage of a job whose order has not arrived yet
+
 // ------------------------------------------------------------------ diagnostics
 // -DFJSP_STAMPS builds a DIAGNOSTIC library (never shipped, never benchmarked): lane 0 of
 // every wave adds the s_memtime delta of each phase of a step to a global table.
@@ -170,8 +178,11 @@ struct W {
     uint32_t status, seq_ctr, rng_calls, busy;
     long long tard_done, delay_sum;
     uint64_t env_seed;
+    int t_arr, next_order, pending, n_orders;      // order arrivals (multi-order batches)
+    const unsigned char *ir;
     // lane = operation type
     uint32_t kA[KC], kB[KC], elig[KC], fmask[KC], first4[KC];
+    int q0[KC], tot[KC];     // fluid_unprocessed_number_start; jobs of the kind that have arrived
     double rate_sum[KC], time_sum[KC];
     int nun[KC], cnt_a[KC], cnt_e[KC], max_a[KC], fifo_cnt[KC], head_job[KC], due_min[KC], tard[KC];
     double max_e[KC], sum_e[KC];
@@ -230,10 +241,18 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         w.kA[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kA)[k];
         w.kB[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kB)[k];
         w.elig[c] = reinterpret_cast<const uint32_t *>(ir + L.i_elig)[k];
-        w.fmask[c] = reinterpret_cast<const uint32_t *>(ir + L.i_fmask)[k];
         w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
-        w.rate_sum[c] = reinterpret_cast<const double *>(ir + L.i_rsum)[k];
-        w.time_sum[c] = reinterpret_cast<const double *>(ir + L.i_tsum)[k];
+        if (V == kMord && load_state) {      // tables of the last LP of THIS environment
+            w.fmask[c] = reinterpret_cast<const uint32_t *>(er + L.e_fmask)[k];
+            w.rate_sum[c] = reinterpret_cast<const double *>(er + L.e_rsum)[k];
+            w.time_sum[c] = reinterpret_cast<const double *>(er + L.e_tsum)[k];
+            w.q0[c] = (int)reinterpret_cast<const uint32_t *>(er + L.e_q0)[k];
+        } else {
+            w.fmask[c] = reinterpret_cast<const uint32_t *>(ir + L.i_fmask)[k];
+            w.rate_sum[c] = reinterpret_cast<const double *>(ir + L.i_rsum)[k];
+            w.time_sum[c] = reinterpret_cast<const double *>(ir + L.i_tsum)[k];
+            w.q0[c] = 0;                     // = jobs of the kind, set below
+        }
     }
     const int32_t due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
     uint32_t jst0 = 0;
@@ -247,6 +266,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         sc.status = es->status; sc.seq_ctr = es->seq_ctr; sc.rng_calls = es->rng_calls; sc.busy = es->busy;
         sc.completion = es->completion; sc.completion_last = es->completion_last;
         sc.tard_done = es->tard_done; sc.delay_sum = es->delay_sum;
+        sc.t_arr = es->t_arr; sc.next_order = es->next_order; sc.pending = es->pending;
         if (w.lane < 10) obs0 = es->obs_prev[w.lane];
         if (w.lane < MP) {
             tend0 = reinterpret_cast<const int32_t *>(er + L.e_tend)[w.lane];
@@ -254,12 +274,20 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         }
     }
     w.p_i = reinterpret_cast<const uint16_t *>(ir + L.i_p);
-    w.col_i = reinterpret_cast<const double *>(ir + L.i_col);
+    w.col_i = reinterpret_cast<const double *>(V == kMord ? er + L.e_col : ir + L.i_col);
+    w.ir = ir;
+    w.t_arr = 0; w.next_order = 1; w.pending = 0;
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
     w.sstate = reinterpret_cast<const double *>(ir + L.i_ss);
     w.fluid_completed_time = w.sstate[7];
     // ---- consume
     w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
+    w.n_orders = V == kMord ? uni(h.R >> 16) : 1;       // InstHeader.R carries S in its high half for multi-order batches
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        w.tot[c] = (int)(w.kA[c] >> 16);
+        if (!(V == kMord && load_state)) w.q0[c] = w.tot[c];
+    }
     w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
     w.dueL[w.lane] = due0;
     for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
@@ -270,6 +298,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.status = uniu(sc.status); w.seq_ctr = uniu(sc.seq_ctr); w.rng_calls = uniu(sc.rng_calls); w.busy = uniu(sc.busy);
     w.completion = uni(sc.completion); w.completion_last = uni(sc.completion_last);
     w.tard_done = sc.tard_done; w.delay_sum = sc.delay_sum;
+    w.t_arr = uni(sc.t_arr); w.next_order = uni((int)sc.next_order); w.pending = uni((int)sc.pending);
     w.obs_prev_l = obs0;
     w.tend_m = w.lane < w.M ? tend0 : 0;
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
@@ -291,6 +320,7 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
         es->status = w.status; es->seq_ctr = w.seq_ctr; es->rng_calls = w.rng_calls; es->busy = w.busy;
         es->completion = w.completion; es->completion_last = w.completion_last;
         es->tard_done = w.tard_done; es->delay_sum = w.delay_sum;
+        es->t_arr = w.t_arr; es->next_order = (int16_t)w.next_order; es->pending = (int16_t)w.pending;
     }
     if (w.lane < 10) reinterpret_cast<EnvScalars *>(er)->obs_prev[w.lane] = w.obs_prev_l;
     if (w.lane < w.M) {
@@ -320,13 +350,14 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
         const uint32_t a = w.kA[c];
         const int jbeg = (int)(a & 0xFFFFu), jcnt = (int)(a >> 16), j = (int)(w.kB[c] & 0xFFu);
         const double ts = w.time_sum[c];
-        int idx = 0, cnt_a = 0, cnt_e = 0, max_a = 0, fifo = 0, head = -1, dmin = 0x7fffffff, tard = 0;
+        int idx = 0, cnt_a = 0, cnt_e = 0, max_a = 0, fifo = 0, head = -1, dmin = 0x7fffffff, tard = 0, arrived = 0;
         uint32_t hseq = 0xFFFFFFFFu;
         double max_e = 0.0, sum_e = 0.0;
         for (int n = jbeg; n < jbeg + jcnt; ++n) {
             const uint32_t js = w.jstL[n];
             const int d = w.dueL[n];            // fetched together with the state word: one LDS latency, not two
             const int nj = (int)(js & 0xFFu);
+            if (V == kMord && nj != (int)kAbsent) arrived++;
             if (nj <= j) {
                 const int da = t - d;                                   // :138
                 const double est = td + ts * (double)(idx + 1);        // :136,139
@@ -348,6 +379,7 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
         w.nun[c] = idx; w.cnt_a[c] = cnt_a; w.cnt_e[c] = cnt_e; w.max_a[c] = max_a; w.max_e[c] = max_e;
         w.fifo_cnt[c] = fifo; w.head_job[c] = head; w.due_min[c] = dmin; w.tard[c] = tard;
         w.sum_e[c] = sum_e;                                             // :153 urgency = sum_e / nun, formed on demand
+        if (V == kMord) w.tot[c] = arrived;
     }
 }
 
@@ -420,12 +452,15 @@ __device__ __forceinline__ bool any_available(const W<KC, V> &w, uint32_t idle) 
     return any != 0;
 }
 
-// fluid_unprocessed_number (SO_FJSSP.py:239-240) is a pure function of the clock
-// (order_arrive_time = 0 for a single order): Q0 - rate_sum * t.
+// gap_time = step_time - order_arrive_time (SO_FJSSP.py:237); order_arrive_time is 0 with a single order
+template <int KC, int V>
+__device__ __forceinline__ double fluid_dt(const W<KC, V> &w) {
+    return (double)(V == kMord ? w.t - w.t_arr : w.t);
+}
+// fluid_unprocessed_number (SO_FJSSP.py:239-240) is a pure function of the clock: Q0 - rate_sum * gap_time
 template <int KC, int V>
 __device__ __forceinline__ double fluid_q(const W<KC, V> &w, int c) {
-    const double q0 = (double)(w.kA[c] >> 16);
-    return q0 - w.rate_sum[c] * (double)w.t;
+    return (double)w.q0[c] - w.rate_sum[c] * fluid_dt(w);
 }
 
 // SO_FJSSP.py:267-298 task_select.  Returns k or -1 (status set).
@@ -512,7 +547,7 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
 template <int KC, int V>
 __device__ __forceinline__ double machine_gap_ave(const W<KC, V> &w, int m) {
     const int KP = w.KP;
-    const double dt = (double)w.t;
+    const double dt = fluid_dt(w);
     double s = 0.0;
     int n = 0;
 #pragma unroll
@@ -556,7 +591,7 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         pm = w.p_i[o];
         un = w.unp[o];
         const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
-        g = un - (ar.x - (double)w.t * ar.y);
+        g = un - (ar.x - fluid_dt(w) * ar.y);
 #endif
     }
     auto visit = [&](const CandList &l, auto &&f) {
@@ -617,10 +652,56 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
     return m_sel;
 }
 
+// reset_object_add(order s) without its LP (class_FJSSP.py:205-237): the jobs of order s enter the stage-0
+// FIFOs in (kind, job number) order, and the LP inputs Q[k] = len(task_unprocessed_list), n_now[k] =
+// len(job_now_list) are written to the env record for the host service.  Only the LAST arrival of a step
+// matters for the tables: nothing inside the event loop reads the fluid solution, and each LP resets the
+// previous one's state.  Returns the number of jobs that arrived.
+template <int KC, int V>
+__device__ __forceinline__ int order_arrive(W<KC, V> &w, const DevBatch *b, int s_ord) {
+    const Layout &L = b->L;
+    const uint16_t *ocnt = reinterpret_cast<const uint16_t *>(w.ir + L.i_ocnt);
+    const int RP = b->RP;
+    int added = 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const uint32_t kb = w.kB[c];
+        const bool first_stage = ((kb >> 24) & 2u) && (kb & 0xFFu) == 0;     // one lane per kind
+        const int r = (int)((kb >> 16) & 0xFFu);
+        int cnt = 0, nstart = 0, before = 0;
+        if (first_stage) {
+            cnt = ocnt[s_ord * RP + r];
+            for (int q = 0; q < s_ord; ++q) nstart += ocnt[q * RP + r];      // Kind.number_start, :212
+            for (int q = 0; q < r; ++q) before += ocnt[s_ord * RP + q];      // jobs of earlier kinds come first
+            const int jbeg = (int)(w.kA[c] & 0xFFFFu);
+            for (int n = 0; n < cnt; ++n)                                    // :216-225
+                w.jstL[jbeg + nstart + n] = jst_pack(w.seq_ctr + (uint32_t)(before + n), 0u);
+            w.fifo_cnt[c] += cnt;
+        }
+        added += wave_sum(cnt);
+    }
+    w.seq_ctr += (uint32_t)added;
+    w.n_unassigned += added;
+    wave_sync();
+    // LP inputs (:234-237): unprocessed tasks per operation type, jobs waiting per operation type
+    uint16_t *lpq = reinterpret_cast<uint16_t *>(w.er + L.e_lpq);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const uint32_t a = w.kA[c];
+        const int jbeg = (int)(a & 0xFFFFu), jcnt = (int)(a >> 16), j = (int)(w.kB[c] & 0xFFu);
+        int q = 0;
+        for (int n = jbeg; n < jbeg + jcnt; ++n) q += ((int)(w.jstL[n] & 0xFFu) <= j) ? 1 : 0;   // absent jobs carry 0xFF
+        const int k = c * kWave + w.lane;
+        if (k < w.K) { lpq[k] = (uint16_t)q; lpq[w.KP + k] = (uint16_t)w.fifo_cnt[c]; }
+    }
+    return added;
+}
+
 // SO_FJSSP.py:176-250: dispatch the FIFO head of k_sel on m_sel, then advance
 // the clock until some operation type is available again (or the episode ends).
 template <int KC, int V>
-__device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, int k_sel, int m_sel, int pm, double un_sel) {
+__device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch *b, int k_sel, int m_sel, int pm,
+                                                     double un_sel) {
     const int KP = w.KP;
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
@@ -666,9 +747,20 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, int k_sel, int
                     if (c == (kk >> 6) && w.lane == (kk & 63)) w.fifo_cnt[c]++;
             }
         }
-        w.busy &= ~(uint32_t)__ballot(w.lane < w.M && w.tend_m <= tn);      // :233-235
+        if (V == kMord && w.next_order < w.n_orders) {                       // :218-231 order arrival
+            const int t_next = reinterpret_cast<const int32_t *>(w.ir + b->L.i_oarr)[w.next_order];
+            const bool due_now = t_next <= w.t, idle_jump = !due_now && w.n_unassigned == 0;
+            if (due_now || idle_jump) {
+                order_arrive<KC, V>(w, b, w.next_order);
+                w.next_order++;
+                w.t_arr = t_next;
+                if (idle_jump) w.t = t_next;                                 // :231 the clock jumps to the arrival
+                w.pending = 1;
+            }
+        }
+        w.busy &= ~(uint32_t)__ballot(w.lane < w.M && w.tend_m <= w.t);     // :233-235
         idle = ~w.busy & w.mmask;
-        if (w.n_unassigned == 0) { w.done = 1; break; }                      // :247-250
+        if (w.n_unassigned == 0 && !(V == kMord && w.next_order < w.n_orders)) { w.done = 1; break; }   // :247-250
     }
     wave_sync();
 }
@@ -714,17 +806,17 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
     double frv[KC], grv[KC];
     bool single_job = true;      // every operation type has exactly one job: the divisions below are x / 1.0 == x
 #pragma unroll
-    for (int c = 0; c < KC; ++c) single_job = single_job && __ballot((w.kA[c] >> 16) > 1u) == 0;
+    for (int c = 0; c < KC; ++c) single_job = single_job && V != kMord && __ballot((w.kA[c] >> 16) > 1u) == 0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-        const int tot = (int)(w.kA[c] >> 16);
+        const int tot = w.tot[c];
         const int k = c * kWave + w.lane;
         const bool valid = k < K;
         const double fnum = (double)(tot - w.nun[c]), gnum = (double)w.nun[c] - fluid_q(w, c);
         if (single_job) { frv[c] = valid ? fnum : 0.0; grv[c] = valid ? gnum : 0.0; }
         else {
             frv[c] = valid ? fnum / (double)tot : 0.0;              // finish_rate class_FJSSP.py:74-76
-            grv[c] = valid ? gnum / (double)tot : 0.0;              // gap_rate    class_FJSSP.py:66-68
+            grv[c] = valid ? gnum / (double)w.q0[c] : 0.0;          // gap_rate    class_FJSSP.py:66-68
         }
         w.frL[k] = frv[c]; w.grL[k] = grv[c];
         w.tdL[k] = (c == 0 && w.lane < M) ? (double)w.tend_m : 0.0;
@@ -762,7 +854,7 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         // updated one element of it, so that store is drained first.
         wave_sync_global();
         const int KP = w.KP;
-        const double dt = (double)w.t;
+        const double dt = fluid_dt(w);
         double gave_m = 0.0;                       // lane m (< M): gap_ave of machine m
         for (int m0 = 0; m0 < M; m0 += 3) {
             int cnt_q[3] = {0, 0, 0};
@@ -815,9 +907,9 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
     const int num = w.lane == 0 ? delay_a : (w.lane == 1 ? delay_e : (w.lane == 2 ? job_a : job_e));
     const int den = w.lane < 2 ? task_number : job_number;
     const double ratio = w.done ? 0.0 : (double)num / (double)den;
-    const int o0 = V == FJSP_VARIANT_SO_FJSSP ? 1 : 0;
+    const int o0 = is_so_v<V> ? 1 : 0;
     if (w.lane == 0) {
-        if (V == FJSP_VARIANT_SO_FJSSP) w.scrL[0] = (double)M;
+        if (is_so_v<V>) w.scrL[0] = (double)M;
         w.scrL[o0] = ct_std; w.scrL[o0 + 1] = cro_ave; w.scrL[o0 + 2] = cro_std; w.scrL[o0 + 3] = gap_ave;
         w.scrL[o0 + 4] = gap_std;
     }
@@ -843,14 +935,40 @@ __device__ __forceinline__ void emit_state(W<KC, V> &w, double *state_out, bool 
 
 // SO_FJSSP.py:51-76 reset (fresh-object semantics; class_FJSSP.py:173-244 for one order).
 template <int KC, int V>
-__device__ __forceinline__ void init_episode(W<KC, V> &w, double *state_out) {
-    const int KP = w.KP;
-    w.t = 0; w.step_count = 0; w.done = 0; w.n_unassigned = w.njobs; w.status = 0;
-    w.seq_ctr = (uint32_t)w.njobs; w.busy = 0; w.completion = 0; w.completion_last = 0;
+__device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, double *state_out) {
+    w.t = 0; w.step_count = 0; w.done = 0; w.status = 0;
+    w.busy = 0; w.completion = 0; w.completion_last = 0;
     w.tard_done = 0; w.delay_sum = 0;
     w.tend_m = 0; w.mjob_m = -1;
-    for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack((uint32_t)n, 0u);  // class_FJSSP.py:225
-    for (int i = w.lane; i < w.K * w.MP; i += kWave) w.unp[i] = w.col_i[2 * i];                  // :304
+    w.t_arr = 0; w.next_order = 1; w.pending = 0;
+    if (V == kMord) {
+        // per-environment copy of the reset-time fluid tables (they change at every later arrival)
+        const Layout &L = b->L;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = c * kWave + w.lane;
+            const int r = (int)((w.kB[c] >> 16) & 0xFFu);
+            w.q0[c] = ((w.kB[c] >> 24) & 2u) ? (int)reinterpret_cast<const uint16_t *>(w.ir + L.i_ocnt)[r] : 0;
+            reinterpret_cast<uint32_t *>(w.er + L.e_fmask)[k] = w.fmask[c];
+            reinterpret_cast<double *>(w.er + L.e_rsum)[k] = w.rate_sum[c];
+            reinterpret_cast<double *>(w.er + L.e_tsum)[k] = w.time_sum[c];
+            reinterpret_cast<uint32_t *>(w.er + L.e_q0)[k] = (uint32_t)w.q0[c];
+            w.fifo_cnt[c] = 0;
+        }
+        const double *src = reinterpret_cast<const double *>(w.ir + L.i_col);
+        double *dst = reinterpret_cast<double *>(w.er + L.e_col);
+        for (int i = w.lane; i < w.K * w.MP * 2; i += kWave) dst[i] = src[i];
+        for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack(kNoSeq, kAbsent);
+        w.seq_ctr = 0; w.n_unassigned = 0;
+        wave_sync();
+        wave_sync_global();
+        order_arrive<KC, V>(w, b, 0);                                                         // class_FJSSP.py:225
+    } else {
+        w.n_unassigned = w.njobs;
+        w.seq_ctr = (uint32_t)w.njobs;
+        for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack((uint32_t)n, 0u);  // class_FJSSP.py:225
+    }
+    for (int i = w.lane; i < w.K * w.MP; i += kWave) w.unp[i] = w.col_i[2 * i];              // :304
     wave_sync();
     wave_sync_global();       // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
     compute_params<KC, V>(w);
@@ -861,8 +979,11 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, double *state_out) {
 // One environment step.  compute_params() must be current on entry and is
 // current again on exit (the fused kernel carries it across steps).
 template <int KC, int V>
-__device__ __forceinline__ double env_step(W<KC, V> &w, int a0, int a1, const double *mo, double *state_out, int *k_out,
-                                           int *m_out) {
+__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out);
+
+template <int KC, int V>
+__device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a0, int a1, const double *mo,
+                                           double *state_out, int *k_out, int *m_out) {
     const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
         if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }   // IndexError
@@ -880,8 +1001,16 @@ __device__ __forceinline__ double env_step(W<KC, V> &w, int a0, int a1, const do
     STAMP(w, 3);
     *k_out = k_sel; *m_out = m_sel;
     if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
-    dispatch_and_advance<KC, V>(w, k_sel, m_sel, pm, un_sel);
+    dispatch_and_advance<KC, V>(w, b, k_sel, m_sel, pm, un_sel);
     STAMP(w, 4);
+    if (V == kMord && w.pending) return 0.0;        // an order arrived: the step is finished by arrival_kernel
+    return env_step_finish<KC, V>(w, mo, state_out);
+}
+
+// Second half of step() (SO_FJSSP.py:252-265): observation, reward, bookkeeping.
+template <int KC, int V>
+__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out) {
+    const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
     w.step_count++;                                                          // :252
     compute_params<KC, V>(w);
     STAMP(w, 5);
@@ -924,8 +1053,13 @@ __global__ void fluid_tables_kernel(DevBatch b) {
     double *col = inst_ptr<double>(b, inst, b.L.i_col) + (size_t)k * MP * 2;
     uint32_t fm = 0;
     double s = 0.0;
-    const double q0 = (double)(inst_ptr<const uint32_t>(b, inst, b.L.i_kA)[k] >> 16);
     const bool valid = k < h.K;
+    // Q0 of the reset-time LP: the jobs of the kind; with several orders only those of order 0
+    double q0 = (double)(inst_ptr<const uint32_t>(b, inst, b.L.i_kA)[k] >> 16);
+    if (b.mord && valid) {
+        const int r = (int)((inst_ptr<const uint32_t>(b, inst, b.L.i_kB)[k] >> 16) & 0xFFu);
+        q0 = (double)inst_ptr<const uint16_t>(b, inst, b.L.i_ocnt)[r];
+    }
     for (int m = 0; m < h.M; ++m) {
         const int pm = p[m];
         double r = 0.0;
@@ -958,7 +1092,7 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
     // rng_calls survives a reset (the reference's global `random` state does too)
     w.rng_calls = env_ptr<const EnvScalars>(b, env, 0)->rng_calls;
     w.obs_prev_l = 0.0;
-    init_episode<KC, V>(w, state_out);
+    init_episode<KC, V>(w, &b, state_out);
     store_dynamic<KC, V>(w, false);
 }
 
@@ -992,7 +1126,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
             }
             return;
         }
-        init_episode<KC, V>(w, nullptr);
+        init_episode<KC, V>(w, &b, nullptr);
     } else {
         compute_params<KC, V>(w);
     }
@@ -1002,7 +1136,19 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
     return;
 #endif
     int k_sel, m_sel;
-    const double reward = env_step<KC, V>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
+    const double reward = env_step<KC, V>(w, &b, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
+    if (V == kMord && w.pending) {
+        // an order arrived inside this step: park the env for the host LP service (fjsp_env.hip), which
+        // finishes the step with arrival_kernel; the outputs of this env are written there
+        if (w.lane == 0) {
+            int16_t *stash = reinterpret_cast<int16_t *>(w.er + b.L.e_lpq) + 2 * b.KP;
+            stash[0] = (int16_t)k_sel; stash[1] = (int16_t)m_sel;
+            const uint32_t slot = atomicAdd(b.pending_count, 1u);
+            b.pending_count[1 + slot] = (uint32_t)env;
+        }
+        store_dynamic<KC, V>(w, false);
+        return;
+    }
     if (w.lane == 0) {
         if (reward_out) reward_out[env] = reward;
         if (done_out) done_out[env] = (uint8_t)w.done;
@@ -1030,7 +1176,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t 
         const bool live = !w.done && !(w.status & (FJSP_ST_BAD_TASK_RULE | FJSP_ST_BAD_MACHINE_RULE | FJSP_ST_NO_EVENT));
         if (live) {
             const int a0 = actions[o * 2], a1 = actions[o * 2 + 1];
-            reward = env_step<KC, V>(w, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel);
+            reward = env_step<KC, V>(w, &b, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel);
         }
         if (w.lane == 0) {
             if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }
@@ -1038,6 +1184,69 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t 
         }
     }
     store_dynamic<KC, V>(w, true);
+}
+
+// Multi-order: finish the step of every env parked at an order arrival.  The host service has solved the
+// fluid LP of the env's live state (class_FJSSP.py:239) and left x in the env record; this kernel runs
+// update_fluid_parameter (:282-306) for that env, then the second half of step().
+template <int KC>
+__global__ __launch_bounds__(256, 4) void arrival_kernel(DevBatch b, int n_pending, double *state_out, double *reward_out,
+                                                         uint8_t *done_out, int16_t *trace_km) {
+    constexpr int V = kMord;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int idx = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (idx >= n_pending) return;
+    const int env = (int)b.pending_count[1 + idx];
+    W<KC, V> w;
+    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
+    const Layout &L = b.L;
+    const double *xin = reinterpret_cast<const double *>(w.er + L.e_xin);
+    const uint16_t *lpq = reinterpret_cast<const uint16_t *>(w.er + L.e_lpq);
+    double *col = reinterpret_cast<double *>(w.er + L.e_col);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int k = c * kWave + w.lane;
+        const bool valid = k < w.K;
+        const double q0 = valid ? (double)lpq[k] : 0.0;
+        uint32_t fm = 0;
+        double ssum = 0.0;
+        for (int m = 0; m < w.M; ++m) {
+            const int o = k * w.MP + m;
+            const int pm = valid ? w.p_i[o] : 0;
+            double r = 0.0;
+            if (pm > 0) {
+                const double xv = xin[o];
+                r = xv * (1.0 / (double)pm);                // :164, :288-289
+                if (xv != 0) fm |= 1u << m;                 // :290-292
+                ssum = ssum + r;                            // :294 (ascending m)
+            }
+            if (valid) col[2 * o + 1] = r;
+        }
+        for (int m = 0; m < w.M; ++m) {
+            const int o = k * w.MP + m;
+            if (!valid) continue;
+            double a = 0.0;
+            if (w.p_i[o] > 0) a = (q0 * col[2 * o + 1]) / ssum;              // :300-302
+            col[2 * o] = a;
+            w.unp[o] = a;                                                    // :304 unprocessed restarts at arrival
+        }
+        w.fmask[c] = fm; w.rate_sum[c] = valid ? ssum : 0.0; w.time_sum[c] = valid ? 1.0 / ssum : 0.0;   // :295
+        w.q0[c] = valid ? (int)lpq[k] : 0;
+        reinterpret_cast<uint32_t *>(w.er + L.e_fmask)[k] = fm;
+        reinterpret_cast<double *>(w.er + L.e_rsum)[k] = w.rate_sum[c];
+        reinterpret_cast<double *>(w.er + L.e_tsum)[k] = w.time_sum[c];
+        reinterpret_cast<uint32_t *>(w.er + L.e_q0)[k] = (uint32_t)w.q0[c];
+    }
+    wave_sync_global();
+    w.pending = 0;
+    const double reward = env_step_finish<KC, V>(w, nullptr, state_out);
+    if (w.lane == 0) {
+        const int16_t *stash = reinterpret_cast<const int16_t *>(w.er + L.e_lpq) + 2 * b.KP;
+        if (reward_out) reward_out[env] = reward;
+        if (done_out) done_out[env] = (uint8_t)w.done;
+        if (trace_km) { trace_km[(size_t)env * 2] = stash[0]; trace_km[(size_t)env * 2 + 1] = stash[1]; }
+    }
+    store_dynamic<KC, V>(w, false);
 }
 
 // attribute read-back: one thread per environment
@@ -1081,6 +1290,7 @@ static int dispatch_kc(int kc, F &&f) {
 }
 template <class F>
 static int dispatch(const DevBatch &b, F &&f) {
+    if (b.mord) return dispatch_kc<kMord>(b.KC, f);
     switch (b.variant) {
     case FJSP_VARIANT_SO_FJSSP: return dispatch_kc<FJSP_VARIANT_SO_FJSSP>(b.KC, f);
     case FJSP_VARIANT_SO_SFJSP: return dispatch_kc<FJSP_VARIANT_SO_SFJSP>(b.KC, f);
@@ -1121,6 +1331,18 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+int launch_arrival(const DevBatch &b, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
+                   hipStream_t st) {
+    const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    const dim3 grid((unsigned)((n_pending + 3) / 4));
+    switch (b.KC) {
+    case 1: hipLaunchKernelGGL((arrival_kernel<1>), grid, dim3(256), lds, st, b, n_pending, state, reward, done, trace_km); break;
+    case 2: hipLaunchKernelGGL((arrival_kernel<2>), grid, dim3(256), lds, st, b, n_pending, state, reward, done, trace_km); break;
+    case 4: hipLaunchKernelGGL((arrival_kernel<4>), grid, dim3(256), lds, st, b, n_pending, state, reward, done, trace_km); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
                 int32_t *step_count, uint8_t *done, uint32_t *status, hipStream_t st) {
     hipLaunchKernelGGL(read_kernel, dim3((unsigned)((b.N + 255) / 256)), dim3(256), 0, st, b, delay, makespan,

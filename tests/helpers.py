@@ -5,10 +5,10 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUITES = ("mk01", "synth10x5", "multijob", "large", "edge")      # SO_FJSSP
+SUITES = ("mk01", "synth10x5", "multijob", "large", "edge", "multiorder")      # SO_FJSSP (multiorder: S > 1)
 MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
 SF_SUITES = ("so_sfjsp",)                                    # SO_SFJSP
-ORACLE_ONLY_SUITES = ("multiorder",)                          # SO_FJSSP with order arrivals: kernels reject S > 1 for now
+ORACLE_ONLY_SUITES = ()
 
 # observation entries that pass through math.pow(x, 2) + sqrt in the reference
 # (SO_FJSSP.py:86-95): glibc pow differs from x*x by 1 ulp in ~0.08 % of arguments,

@@ -65,14 +65,16 @@ def test_env_create_without_gpu_or_bad_args_errors(built):
             EnvBatch(s, 4)
 
 
-def test_multi_order_instances_are_rejected_loudly_not_approximated(built):
-    """S > 1 needs an LP re-solve at every order arrival; until the kernels do that the library refuses."""
+def test_subclass_variants_refuse_multi_order_instances(built):
+    """SO_SFJSP / MO_FJSSP_discretes are single-order in the reference (they only ever add order_dict[0]);
+    the library refuses to build them on an instance with several orders instead of silently dropping orders."""
     from deep_reinforcement_learning_for_fjsp_amd import _capi
     insts, _, _ = H.load_suite("multiorder")
     s = H.instance_set_from(insts[1:2])
     h = C.c_void_p()
-    assert _capi.lib().fjsp_env_create(s.handle, 0, 1, 2, 0, 0, 0, C.byref(h)) == -5
-    assert b"multi-order" in _capi.lib().fjsp_last_error()
+    for variant in (1, 2):
+        assert _capi.lib().fjsp_env_create(s.handle, 0, 1, 2, variant, 0, 0, C.byref(h)) == -5
+        assert b"single-order" in _capi.lib().fjsp_last_error()
 
 
 def _write_csv(arr, folder):
