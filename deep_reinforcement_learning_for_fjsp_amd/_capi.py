@@ -33,6 +33,9 @@ SIGNATURES = {
     "fjsp_instances_set_raw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl]),
     "fjsp_instances_dims": (C.c_int, [_vp, _i32, C.POINTER(_i32 * 6)]),
     "fjsp_instances_get": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_dbl), _vp]),
+    "fjsp_instances_dynamic_dims": (C.c_int, [_vp, _i32, C.POINTER(_i32 * 2)]),
+    "fjsp_instances_get_dynamic": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "fjsp_instances_set_dynamic": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "fjsp_instances_solve_fluid": (C.c_int, [_vp, _i32, _i32, _i32]),
     "fjsp_instances_set_x": (C.c_int, [_vp, _i32, _vp]),
     "fjsp_fluid_lp": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_dbl)]),

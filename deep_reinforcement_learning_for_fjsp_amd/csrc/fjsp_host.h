@@ -17,6 +17,12 @@ struct Instance {
     std::vector<int> elig_list;       // [K*M] machine_rj_dict[(r,j)] in file order
     std::vector<int> count;           // [S*R]
     std::vector<int> arrive, delivery;// [S]
+    // dynamic multi-objective instances (MO_DFJSP_instance_read.py): powers and machine breakdown windows
+    bool has_dynamic = false;
+    std::vector<int> power;           // [K*M] power_mrj_dict (0 where ineligible)
+    std::vector<int> idle_power;      // [M]   power_m_dict
+    std::vector<int> bk_n;            // [M]   number of breakdown windows of machine m
+    std::vector<int> bk;              // flattened (start, end) pairs, machine-major, file order; bk_off[m] = prefix of bk_n
     double ddt = 0.0;                 // self.DDT as the source parsed it
     std::vector<double> x;            // [K*M] fluid solution (input of the kernels)
     bool has_x = false;

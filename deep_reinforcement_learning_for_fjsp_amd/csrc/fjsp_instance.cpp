@@ -140,13 +140,14 @@ static int load_csv(Instance &in, const std::string &dir) {
         set_error("cannot read " + dir + "/process_data.csv"); return FJSP_E_IO;
     }
     in.Jr.assign(in.R, 0);
-    struct Row { int r, j; std::vector<int> ms, ts; };
+    struct Row { int r, j; std::vector<int> ms, ts, ps; };
     std::vector<Row> prow;
     for (size_t i = 1; i < rows.size(); ++i) {
         if (rows[i].size() < 4) { set_error("process_data.csv: short row"); return FJSP_E_FORMAT; }
         Row w;
         if (!first_int(rows[i][0], w.r) || !first_int(rows[i][1], w.j)) { set_error("process_data.csv: non-numeric"); return FJSP_E_FORMAT; }
         w.ms = digits(rows[i][2]); w.ts = digits(rows[i][3]);
+        if (rows[i].size() >= 5) w.ps = digits(rows[i][4]);     // power column (MO_DFJSP_instance_read.py:84)
         if (w.r < 0 || w.r >= in.R) { set_error("process_data.csv: kind out of range"); return FJSP_E_FORMAT; }
         // task labels must be 0..J_r-1 in file order: the LP's (r, j+1) arithmetic
         // (class_FJSSP.py:270-271) assumes it.
@@ -178,7 +179,46 @@ static int load_csv(Instance &in, const std::string &dir) {
             in.elig_list[(size_t)k * in.M + in.elig_n[k]++] = w.ms[q];
         }
     }
-    return finalize_instance(in);
+    // machine_data.csv (MO_DFJSP_instance_read.py:56-73): idle power per machine and breakdown windows;
+    // present only in the dynamic multi-objective folders (data/HMPSAC, data/industrial)
+    std::vector<std::vector<std::string>> mrows;
+    if (read_csv(dir + "/machine_data.csv", mrows) && mrows.size() >= 2) {
+        in.has_dynamic = true;
+        in.power.assign(km, 0);
+        for (const Row &w : prow) {
+            int k = in.koff[w.r] + w.j;
+            for (size_t q = 0; q < std::min(w.ms.size(), w.ps.size()); ++q) in.power[(size_t)k * in.M + w.ms[q]] = w.ps[q];
+        }
+        in.idle_power.assign(in.M, -1);
+        std::vector<std::vector<int>> win(in.M);
+        for (size_t i = 1; i < mrows.size(); ++i) {
+            int m, ip;
+            if (mrows[i].size() < 2 || !first_int(mrows[i][0], m) || !first_int(mrows[i][1], ip) || m < 0 || m >= in.M) {
+                set_error("machine_data.csv: bad row"); return FJSP_E_FORMAT;
+            }
+            if (in.idle_power[m] < 0) in.idle_power[m] = ip;          // first row of a machine sets the idle power (:65-66)
+            if (mrows[i].size() > 2) {                                // breakdown window (:68-71)
+                int bs, be;
+                if (mrows[i].size() < 4 || !first_int(mrows[i][2], bs) || !first_int(mrows[i][3], be)) {
+                    set_error("machine_data.csv: bad breakdown window"); return FJSP_E_FORMAT;
+                }
+                win[m].push_back(bs); win[m].push_back(be);
+            }
+        }
+        in.bk_n.assign(in.M, 0);
+        for (int m = 0; m < in.M; ++m) {
+            if (in.idle_power[m] < 0) { set_error("machine_data.csv: machine without a row"); return FJSP_E_FORMAT; }
+            in.bk_n[m] = (int)win[m].size() / 2;
+            in.bk.insert(in.bk.end(), win[m].begin(), win[m].end());
+        }
+    }
+    {
+        const bool dyn = in.has_dynamic;
+        std::vector<int> power = in.power, idle = in.idle_power, bkn = in.bk_n, bk = in.bk;
+        int rc = finalize_instance(in);
+        in.has_dynamic = dyn; in.power = power; in.idle_power = idle; in.bk_n = bkn; in.bk = bk;
+        return rc;
+    }
 }
 
 // ---- counter-based generator ----------------------------------------------
@@ -354,6 +394,43 @@ int fjsp_instances_get(const fjsp_instances *s, int32_t i, int32_t *Jr, int32_t 
     if (delivery) std::copy(in.delivery.begin(), in.delivery.end(), delivery);
     if (ddt) *ddt = in.ddt;
     if (x) std::copy(in.x.begin(), in.x.end(), x);
+    return FJSP_OK;
+}
+
+int fjsp_instances_dynamic_dims(const fjsp_instances *s, int32_t i, int32_t dims[2]) {
+    CHECK_IDX(s, i);
+    const Instance &in = s->v[(size_t)i];
+    if (!in.valid) { set_error("instance not populated"); return FJSP_E_STATE; }
+    dims[0] = in.has_dynamic ? 1 : 0;
+    dims[1] = (int)in.bk.size() / 2;
+    return FJSP_OK;
+}
+
+int fjsp_instances_get_dynamic(const fjsp_instances *s, int32_t i, int32_t *power, int32_t *idle_power, int32_t *bk_n,
+                               int32_t *bk) {
+    CHECK_IDX(s, i);
+    const Instance &in = s->v[(size_t)i];
+    if (!in.valid || !in.has_dynamic) { set_error("instance has no machine data"); return FJSP_E_STATE; }
+    if (power) std::copy(in.power.begin(), in.power.end(), power);
+    if (idle_power) std::copy(in.idle_power.begin(), in.idle_power.end(), idle_power);
+    if (bk_n) std::copy(in.bk_n.begin(), in.bk_n.end(), bk_n);
+    if (bk) std::copy(in.bk.begin(), in.bk.end(), bk);
+    return FJSP_OK;
+}
+
+int fjsp_instances_set_dynamic(fjsp_instances *s, int32_t i, const int32_t *power, const int32_t *idle_power,
+                               const int32_t *bk_n, const int32_t *bk) {
+    CHECK_IDX(s, i);
+    Instance &in = s->v[(size_t)i];
+    if (!in.valid || !power || !idle_power || !bk_n) { set_error("set_dynamic: bad arguments"); return FJSP_E_ARG; }
+    in.power.assign(power, power + (size_t)in.K * in.M);
+    in.idle_power.assign(idle_power, idle_power + in.M);
+    in.bk_n.assign(bk_n, bk_n + in.M);
+    int total = 0;
+    for (int m = 0; m < in.M; ++m) { if (bk_n[m] < 0) { set_error("set_dynamic: negative window count"); return FJSP_E_ARG; } total += bk_n[m]; }
+    if (total > 0 && !bk) { set_error("set_dynamic: windows missing"); return FJSP_E_ARG; }
+    in.bk.assign(bk, bk + (size_t)total * 2);
+    in.has_dynamic = true;
     return FJSP_OK;
 }
 

@@ -129,7 +129,28 @@ class InstanceSet(object):
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)
         check(self._lib.fjsp_instances_get(self._h, int(i), ptr(Jr), ptr(p), ptr(elig_n), ptr(elig_list), ptr(count),
                                            ptr(arrive), ptr(delivery), C.byref(ddt), ptr(x)))
-        return InstanceArrays(R, M, K, S, Jr, p, elig_n, elig_list, count, arrive, delivery, ddt.value, x)
+        out = InstanceArrays(R, M, K, S, Jr, p, elig_n, elig_list, count, arrive, delivery, ddt.value, x)
+        dd = (C.c_int32 * 2)()
+        check(self._lib.fjsp_instances_dynamic_dims(self._h, int(i), C.byref(dd)))
+        if dd[0]:       # MO_DFJSP_instance_read.py extras: powers + breakdown windows
+            out.power = np.zeros((K, M), np.int32)
+            out.idle_power = np.zeros(M, np.int32)
+            out.bk_n = np.zeros(M, np.int32)
+            out.bk = np.zeros((max(dd[1], 1), 2), np.int32)
+            check(self._lib.fjsp_instances_get_dynamic(self._h, int(i), ptr(out.power), ptr(out.idle_power), ptr(out.bk_n),
+                                                       ptr(out.bk)))
+            out.bk = out.bk[:dd[1]]
+        return out
+
+    def set_dynamic(self, i, power, idle_power, bk_n, bk):
+        power = np.ascontiguousarray(power, dtype=np.int32)
+        idle_power = np.ascontiguousarray(idle_power, dtype=np.int32)
+        bk_n = np.ascontiguousarray(bk_n, dtype=np.int32)
+        bk = np.ascontiguousarray(bk, dtype=np.int32).reshape(-1)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(self._lib.fjsp_instances_set_dynamic(self._h, int(i), ptr(power), ptr(idle_power), ptr(bk_n),
+                                                   ptr(bk) if len(bk) else None))
+        return self
 
 
 def fluid_lp(Jr, p, Q, n_now):

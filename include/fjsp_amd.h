@@ -101,6 +101,17 @@ int fjsp_instances_get(const fjsp_instances *s, int32_t i, int32_t *Jr, int32_t 
                        int32_t *elig_list, int32_t *count, int32_t *arrive, int32_t *delivery,
                        double *ddt, double *x /*[K*M] k-major, fluid solution or zeros*/);
 
+/* Dynamic multi-objective folders (environments/MO_DFJSP_instance_read.py:6-108: process_data.csv carries a
+ * power column, machine_data.csv the idle power and the breakdown windows of every machine); load_csv reads
+ * them when machine_data.csv exists.  dims[0] = 1 if present, dims[1] = total number of breakdown windows.
+ * power[K*M] k-major (0 = ineligible), idle_power[M], bk_n[M] windows per machine, bk[2*total] flattened
+ * (start, end) pairs machine-major in file order. */
+int fjsp_instances_dynamic_dims(const fjsp_instances *s, int32_t i, int32_t dims[2]);
+int fjsp_instances_get_dynamic(const fjsp_instances *s, int32_t i, int32_t *power, int32_t *idle_power,
+                               int32_t *bk_n, int32_t *bk);
+int fjsp_instances_set_dynamic(fjsp_instances *s, int32_t i, const int32_t *power, const int32_t *idle_power,
+                               const int32_t *bk_n, const int32_t *bk);
+
 /* FJSP.fluid_model() for the reset-time state (environments/class_FJSSP.py:246-280):
  * solves the fluid LP of instances [first, first+n) with the library's own
  * deterministic vertex simplex on n_threads host threads and stores x. */

@@ -177,6 +177,11 @@ struct fjo_env {
     double obs[16], last_obs[16];
     double static_state[8];
     int n_obs, n_static;
+    /* MO_DFJSP(_breakdown): powers, breakdown windows, energy (class_MODFJSP.py:176-178, MO_DFJSP_instance_read.py:56-73) */
+    int *power, *idle_power, *bk_n, *bk_off, *bk;
+    int *tlast, *ntask;         /* per machine: time_end of its last task, len(task_list) */
+    int64_t energy, energy_last;
+    int order_count_attr;
 };
 
 static uint64_t splitmix64(uint64_t z) {
@@ -195,7 +200,7 @@ static int rng_choice(fjo_env *e, int n) {
 static long py_round(double v) { return (long)nearbyint(v); }
 
 fjo_env *fjo_create(const fjo_instance *in, int variant) {
-    if (variant != FJO_SO_FJSSP && variant != FJO_SO_SFJSP && variant != FJO_MO_FJSSP_DISCRETES) return NULL;
+    if (variant != FJO_SO_FJSSP && variant != FJO_SO_SFJSP && variant != FJO_MO_FJSSP_DISCRETES && variant != FJO_MO_DFJSP) return NULL;
     fjo_env *e = (fjo_env *)calloc(1, sizeof(*e));
     e->variant = variant;
     e->R = in->R; e->M = in->M; e->K = in->K; e->S = in->S;
@@ -242,6 +247,9 @@ fjo_env *fjo_create(const fjo_instance *in, int variant) {
     e->n_obs = 10; e->n_static = 0;
     if (variant == FJO_MO_FJSSP_DISCRETES) { e->n_obs = 9; e->n_static = 7; }
     if (variant == FJO_SO_SFJSP) { e->n_obs = 9; e->n_static = 0; }
+    if (variant == FJO_MO_DFJSP) { e->n_obs = 15; e->n_static = 0; }
+    e->tlast = (int *)calloc((size_t)M, sizeof(int));
+    e->ntask = (int *)calloc((size_t)M, sizeof(int));
     return e;
 }
 
@@ -258,10 +266,22 @@ void fjo_destroy(fjo_env *e) {
     free(e->time_sum); free(e->fl_n); free(e->fl_list); free(e->mstate); free(e->tend); free(e->mjob);
     free(e->rate); free(e->arr); free(e->un); free(e->fu); free(e->x); free(e->delay_time_a);
     free(e->delay_time_e); free(e->urgency); free(e->due_min); free(e->jobs);
+    free(e->power); free(e->idle_power); free(e->bk_n); free(e->bk_off); free(e->bk); free(e->tlast); free(e->ntask);
     free(e);
 }
 
 void fjo_set_lp(fjo_env *e, fjo_lp_fn fn, void *user) { e->lp = fn; e->lp_user = user; }
+void fjo_set_dynamic(fjo_env *e, const int *power, const int *idle_power, const int *bk_n, const int *bk) {
+    int K = e->K, M = e->M, tot = 0;
+    e->power = (int *)malloc(sizeof(int) * (size_t)K * M); memcpy(e->power, power, sizeof(int) * (size_t)K * M);
+    e->idle_power = (int *)malloc(sizeof(int) * (size_t)M); memcpy(e->idle_power, idle_power, sizeof(int) * (size_t)M);
+    e->bk_n = (int *)malloc(sizeof(int) * (size_t)M); memcpy(e->bk_n, bk_n, sizeof(int) * (size_t)M);
+    e->bk_off = (int *)calloc((size_t)M + 1, sizeof(int));
+    for (int m = 0; m < M; ++m) { e->bk_off[m] = tot; tot += bk_n[m]; }
+    e->bk_off[M] = tot;
+    e->bk = (int *)malloc(sizeof(int) * (size_t)(2 * tot + 2));
+    if (tot) memcpy(e->bk, bk, sizeof(int) * (size_t)tot * 2);
+}
 void fjo_set_rng(fjo_env *e, uint64_t seed) { e->rng_seed = seed; e->rng_calls = 0; }
 int  fjo_state_size(const fjo_env *e) { return e->n_static + 2 * e->n_obs; }
 
@@ -272,7 +292,7 @@ int  fjo_state_size(const fjo_env *e) { return e->n_static + 2 * e->n_obs; }
 static void reset_parameter(fjo_env *e) {
     for (int r = 0; r < e->R; ++r) { e->kind_arrived[r] = 0; il_clear(&e->kind_unproc[r]); }
     for (int k = 0; k < e->K; ++k) { il_clear(&e->job_now[k]); il_clear(&e->job_unproc[k]); e->processed[k] = 0; }
-    for (int m = 0; m < e->M; ++m) { e->mstate[m] = 0; e->tend[m] = 0; e->mjob[m] = -1; }
+    for (int m = 0; m < e->M; ++m) { e->mstate[m] = 0; e->tend[m] = 0; e->mjob[m] = -1; e->tlast[m] = 0; e->ntask[m] = 0; }
     e->njobs = 0;
 }
 
@@ -322,7 +342,8 @@ static int reset_object_add(fjo_env *e, int s) {
             int id = e->njobs++;
             job_t *jb = &e->jobs[id];
             jb->kind = r; jb->n = n; jb->next_j = 0; jb->time_arrive = e->arrive[s];
-            jb->due = (int)py_round((double)(r_due * n) / (double)cnt);           /* :218 */
+            jb->due = (e->variant == FJO_MO_DFJSP) ? e->delivery[s]                 /* class_MODFJSP.py:224 */
+                                                   : (int)py_round((double)(r_due * n) / (double)cnt);           /* :218 */
             e->kind_arrived[r]++;
             il_push(&e->kind_unproc[r], id);
             il_push(&e->job_now[e->koff[r]], id);                                  /* :225 */
@@ -391,6 +412,7 @@ static double machine_gap_rj(const fjo_env *e, int m, int k) { return e->un[k * 
 static double machine_gap_ave(const fjo_env *e, int m) {
     double s = 0.0;
     for (int i = 0; i < e->ktm[m].n; ++i) s = s + machine_gap_rj(e, m, e->ktm[m].v[i]);
+    if (e->variant == FJO_MO_DFJSP) return s / (double)e->ktm[m].n;             /* class_MODFJSP.py:158-159 */
     return s / ((double)e->ktm[m].n + 1e-18);
 }
 
@@ -462,6 +484,24 @@ static void state_extract(fjo_env *e, double *o) {
     double s = 0.0;
     for (int m = 0; m < M; ++m) s = s + pow((double)e->tend[m] - ct_m_ave, 2.0);
     double ct_m_std = sqrt(s / (double)M);
+    if (e->variant == FJO_MO_DFJSP) {                                           /* MO_DFJSP_breakdown.py:94-118 */
+        int tmp[4096];
+        double ratio_idle = (double)available_list(e, 1, tmp) / ((double)available_list(e, 0, tmp) + 1e-08);
+        double cro_a = mean_k(e, tasks_finish_rate), cro_s = pop_std_k(e, tasks_finish_rate, cro_a);
+        double gap_a = mean_k(e, tasks_gap_rate), gap_s = pop_std_k(e, tasks_gap_rate, gap_a);
+        double gs = 0.0;
+        for (int m = 0; m < M; ++m) gs = gs + machine_gap_ave(e, m);
+        double gap_m_ave = gs / (double)M;
+        double g2 = 0.0;
+        for (int m = 0; m < M; ++m) g2 = g2 + pow(machine_gap_ave(e, m) - gap_m_ave, 2.0);
+        double gap_m_std = sqrt(g2 / (double)M);
+        double da, de, ja, je;
+        update_parameter(e, &da, &de, &ja, &je);
+        o[0] = e->static_state[0]; o[1] = (double)M; o[2] = (double)e->S; o[3] = ct_m_std; o[4] = ratio_idle;
+        o[5] = cro_a; o[6] = cro_s; o[7] = gap_a; o[8] = gap_s; o[9] = gap_m_ave; o[10] = gap_m_std;
+        o[11] = da; o[12] = de; o[13] = ja; o[14] = je;
+        return;
+    }
     if (e->variant == FJO_SO_SFJSP) {                                           /* SO_SFJSP.py:64-83 */
         int tmp[4096];
         double M_idle_ratio = (double)machine_idle_list(e, tmp) / (double)M;
@@ -517,6 +557,7 @@ int fjo_reset(fjo_env *e, double *state) {
     if (rc) return rc;
     e->delay_sum_last = e->delay_sum = e->delay_processed = e->delay_unprocessed = 0;
     e->completion_time = e->completion_time_last = 0;
+    e->energy = e->energy_last = 0;
     e->step_count = 0; e->step_time = 0; e->order_arrive_time = 0; e->done = 0;
     if (e->variant == FJO_MO_FJSSP_DISCRETES) static_state_extract(e, e->static_state[0]);
     state_extract(e, e->last_obs);
@@ -534,6 +575,17 @@ static int time_min_rj(fjo_env *e, int k, int fluid) {
                   : fjo_pyset_and_list(idle, nidle, &e->elig_list[k * e->M], e->elig_n[k], sel);
     int best = e->p[k * e->M + sel[0]];
     for (int i = 1; i < n; ++i) if (e->p[k * e->M + sel[i]] < best) best = e->p[k * e->M + sel[i]];
+    return best;
+}
+
+/* MO_DFJSP_breakdown.py:498-508 energy_min_rj / energy_min_fluid_rj */
+static long energy_min_rj(fjo_env *e, int k, int fluid) {
+    int idle[1024], sel[1024];
+    int nidle = machine_idle_list(e, idle);
+    int n = fluid ? fjo_pyset_and_list(idle, nidle, &e->fl_list[k * e->M], e->fl_n[k], sel)
+                  : fjo_pyset_and_list(idle, nidle, &e->elig_list[k * e->M], e->elig_n[k], sel);
+    long best = (long)e->power[k * e->M + sel[0]] * e->p[k * e->M + sel[0]];
+    for (int i = 1; i < n; ++i) { long v = (long)e->power[k * e->M + sel[i]] * e->p[k * e->M + sel[i]]; if (v < best) best = v; }
     return best;
 }
 
@@ -557,6 +609,27 @@ static int task_select(fjo_env *e, int rule) {
             for (int i = 0; i < n; ++i) { int v = time_min_rj(e, l[i], fluid); if (b < 0 || v < bv) { bv = v; b = l[i]; } }
             return b; }
         case 4: return av[rng_choice(e, nav)];
+        default: return -1;
+        }
+    }
+    if (e->variant == FJO_MO_DFJSP && rule >= 6) {                              /* MO_DFJSP_breakdown.py:357-381 */
+        int nf = available_list(e, 1, fav);
+        switch (rule) {
+        case 6: { int b = av[0]; for (int i = 1; i < nav; ++i) if (e->due_min[av[i]] < e->due_min[b]) b = av[i]; return b; }
+        case 7: case 8: {
+            int fluid = (rule == 7 && nf > 0);
+            const int *l = fluid ? fav : av; int n = fluid ? nf : nav;
+            int b = -1; long bv = 0;
+            for (int i = 0; i < n; ++i) { long v = energy_min_rj(e, l[i], fluid); if (b < 0 || v < bv) { bv = v; b = l[i]; } }
+            return b; }
+        case 9: case 10: {
+            int fluid = (rule == 9 && nf > 0);
+            const int *l = fluid ? fav : av; int n = fluid ? nf : nav;
+            int b = -1, bv = 0;
+            for (int i = 0; i < n; ++i) { int v = time_min_rj(e, l[i], fluid); if (b < 0 || v < bv) { bv = v; b = l[i]; } }
+            return b; }
+        case 11: return nf ? fav[rng_choice(e, nf)] : av[rng_choice(e, nav)];
+        case 12: return av[rng_choice(e, nav)];
         default: return -1;
         }
     }
@@ -617,6 +690,25 @@ static int machine_select(fjo_env *e, int rule, int k) {
         default: return -2;
         }
     }
+    if (e->variant == FJO_MO_DFJSP) {                                           /* MO_DFJSP_breakdown.py:384-428 */
+#define ARGMIN_E(list, n) ({ int _b = (list)[0]; \
+        for (int _i = 1; _i < (n); ++_i) { if ((long)e->power[k * M + (list)[_i]] * e->p[k * M + (list)[_i]] < (long)e->power[k * M + _b] * e->p[k * M + _b]) _b = (list)[_i]; } _b; })
+#define ARGMIN_IDLE(list, n) ({ int _b = (list)[0]; \
+        for (int _i = 1; _i < (n); ++_i) { if (e->idle_power[(list)[_i]] < e->idle_power[_b]) _b = (list)[_i]; } _b; })
+        switch (rule) {
+        case 1: return nfs == 0 ? ARGMAX_GAP(sel, nsel) : ARGMAX_GAP(fsel, nfs);
+        case 2: return nfs == 0 ? ARGMIN_P(sel, nsel) : ARGMIN_P(fsel, nfs);
+        case 3: return ARGMIN_P(sel, nsel);
+        case 4: return nfs == 0 ? ARGMAX_GAVE(sel, nsel) : ARGMAX_GAVE(fsel, nfs);
+        case 5: return nfs == 0 ? ARGMIN_E(sel, nsel) : ARGMIN_E(fsel, nfs);
+        case 6: return ARGMIN_E(sel, nsel);
+        case 7: return nfs == 0 ? ARGMIN_IDLE(sel, nsel) : ARGMIN_IDLE(fsel, nfs);
+        case 8: return ARGMIN_IDLE(sel, nsel);
+        case 9: return nfs == 0 ? sel[rng_choice(e, nsel)] : fsel[rng_choice(e, nfs)];
+        case 10: return sel[rng_choice(e, nsel)];
+        default: return -2;
+        }
+    }
     if (e->variant == FJO_SO_SFJSP) {                                           /* SO_SFJSP.py:190-214 */
         switch (rule) {
         case 1: return nfs == 0 ? ARGMAX_GAP(sel, nsel) : ARGMAX_GAP(fsel, nfs);
@@ -654,11 +746,28 @@ static int step_core(fjo_env *e, int task_rule, int machine_rule, double *state,
     int job = e->job_now[k].v[0];                                              /* :176 */
     job_t *jb = &e->jobs[job];
     int time_end = e->step_time + e->p[k * M + m];                             /* :184 */
+    int machine_end = time_end;
+    if (e->variant == FJO_MO_DFJSP) {                                          /* MO_DFJSP_breakdown.py:204-231 */
+        int cur = e->step_time;
+        for (int q = e->bk_off[m]; q < e->bk_off[m + 1]; ++q) {
+            int bs = e->bk[2 * q], be = e->bk[2 * q + 1];
+            if (bs <= cur && cur < be) { int d = be - cur; time_end += d; machine_end = time_end; }
+            else if (cur < bs && bs < time_end) { int d = be - bs; time_end += d; machine_end = time_end; }
+            else if (bs == time_end) machine_end += (be - bs);
+            else if (bs > time_end) break;
+        }
+    }
     jb->next_j++;                                                              /* :186-187 */
     il_remove(&e->job_now[k], job);                                            /* :189 */
     il_remove(&e->job_unproc[k], job);                                         /* :190-191 */
     e->processed[k]++;                                                         /* :192 */
-    e->mstate[m] = 1; e->tend[m] = time_end; e->mjob[m] = job;                 /* :194-197 */
+    e->mstate[m] = 1; e->tend[m] = machine_end; e->mjob[m] = job;              /* :194-197 (machine_end_time for the dynamic env) */
+    if (e->variant == FJO_MO_DFJSP) {                                          /* MO_DFJSP_breakdown.py:253-256 */
+        e->energy += (int64_t)e->power[k * M + m] * e->p[k * M + m];
+        e->ntask[m]++;
+        if (e->ntask[m] >= 2) e->energy += (int64_t)(e->step_time - e->tlast[m]) * e->idle_power[m];
+        e->tlast[m] = time_end;
+    }
     e->un[k * M + m] -= 1;                                                     /* :198 */
     if (time_end > e->completion_time) e->completion_time = time_end;          /* MO_FJSSP_discretes.py:122 */
     if (jb->next_j == e->Jr[jb->kind]) {                                       /* :200-202 */
@@ -680,7 +789,7 @@ static int step_core(fjo_env *e, int task_rule, int machine_rule, double *state,
                 job_t *b2 = &e->jobs[j2];
                 if (b2->next_j < e->Jr[b2->kind]) il_push(&e->job_now[e->koff[b2->kind] + b2->next_j], j2);
             }
-        if (e->variant == FJO_SO_FJSSP) {
+        if (e->variant == FJO_SO_FJSSP || e->variant == FJO_MO_DFJSP) {
             if (e->next_order < e->S && e->arrive[e->next_order] <= e->step_time) {       /* :218-223 */
                 int s = e->next_order++;
                 int rc = reset_object_add(e, s); if (rc) return rc;
@@ -701,7 +810,7 @@ static int step_core(fjo_env *e, int task_rule, int machine_rule, double *state,
                 int kk = e->ktm[mm].v[i];
                 e->fu[kk * M + mm] = e->arr[kk * M + mm] - (double)gap_time * e->rate[kk * M + mm];
             }
-        int orders_left = (e->variant == FJO_SO_FJSSP) ? (e->S - e->next_order) : 0;
+        int orders_left = (e->variant == FJO_SO_FJSSP || e->variant == FJO_MO_DFJSP) ? (e->S - e->next_order) : 0;
         if (orders_left == 0 && unfinished_jobs(e) == 0) { e->done = 1; break; }           /* :247-250 */
     }
     e->step_count++;                                                           /* :252 */
@@ -745,6 +854,29 @@ int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion,
     return 0;
 }
 void fjo_set_ddt(fjo_env *e, double ddt) { e->static_state[0] = ddt; }
+
+/* MO_DFJSP_breakdown.py:189-328 step(action, reward_policy, completion, tardiness, energy_consumption);
+ * compute_reward :430-447. */
+int fjo_step_dyn(fjo_env *e, int a0, int a1, int policy, double completion, double tardiness, double energy,
+                 double *state, double *reward, int *done, fjo_trace *tr) {
+    if (e->variant != FJO_MO_DFJSP) return -6;
+    int rc = step_core(e, a0 + 1, a1 + 1, state, tr);
+    if (rc) return rc;
+    double dc = (double)(e->completion_time_last - e->completion_time);
+    double dt = (double)(e->delay_sum_last - e->delay_sum);
+    double de = (double)(e->energy_last - e->energy);
+    if (policy == 0) *reward = dc;
+    else if (policy == 1) *reward = dt;
+    else if (policy == 2) *reward = de;
+    else if (policy == 3) *reward = tardiness > 0 ? dc / completion + dt / tardiness + de / energy : dc / completion + de / energy;
+    else return -7;
+    e->delay_sum_last = e->delay_sum;
+    e->completion_time_last = e->completion_time;
+    e->energy_last = e->energy;
+    *done = e->done;
+    return 0;
+}
+int64_t fjo_energy(const fjo_env *e) { return e->energy; }
 
 /* SO_SFJSP.py:85-167 step(action): actions table :25 = (task_rule in range(4)) x (machine_rule in range(5));
  * reward :216-222 = -(completion_time - completion_time_last) / fluid_completed_time.

@@ -51,7 +51,7 @@ typedef struct {
 } fjo_trace;
 
 /* Variants share one skeleton. */
-enum { FJO_SO_FJSSP = 0, FJO_SO_SFJSP = 1, FJO_MO_FJSSP_DISCRETES = 2 };
+enum { FJO_SO_FJSSP = 0, FJO_SO_SFJSP = 1, FJO_MO_FJSSP_DISCRETES = 2, FJO_MO_DFJSP = 4 };
 
 fjo_env *fjo_create(const fjo_instance *inst, int variant);
 void     fjo_destroy(fjo_env *e);
@@ -70,6 +70,14 @@ int fjo_step(fjo_env *e, int a0, int a1, double *state, double *reward, int *don
  * completion/tardiness <= 0 stand for None. */
 int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion, double tardiness,
                 double *state, double *reward, int *done, fjo_trace *tr);
+/* MO_DFJSP(_breakdown).py: machine data of the dynamic multi-objective env (power[K*M] k-major, idle_power[M],
+ * bk_n[M] breakdown windows per machine, bk[] flattened (start, end) pairs machine-major; all zero windows
+ * = MO_DFJSP.py).  Must be called before fjo_reset for variant FJO_MO_DFJSP. */
+void fjo_set_dynamic(fjo_env *e, const int *power, const int *idle_power, const int *bk_n, const int *bk);
+/* MO_DFJSP_breakdown.py:189 step(action, reward_policy, completion, tardiness, energy_consumption) */
+int fjo_step_dyn(fjo_env *e, int a0, int a1, int policy, double completion, double tardiness, double energy,
+                 double *state, double *reward, int *done, fjo_trace *tr);
+int64_t fjo_energy(const fjo_env *e);
 /* SO_SFJSP.py:85 step(action): flat action in [0, 20). */
 int fjo_step_sf(fjo_env *e, int action, double *state, double *reward, int *done, fjo_trace *tr);
 /* self.DDT as the instance source parsed it (static state element 0 of the MO variant). */

@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, "libfjsp_oracle.so")
 SO_FJSSP = 0
 SO_SFJSP = 1
 MO_FJSSP_DISCRETES = 2
+MO_DFJSP = 4
 
 
 class _Inst(C.Structure):
@@ -51,6 +52,11 @@ def lib():
                                C.POINTER(Trace)]
         L.fjo_step_mo.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(Trace)]
+        L.fjo_set_dynamic.argtypes = [C.c_void_p] * 5
+        L.fjo_step_dyn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(Trace)]
+        L.fjo_energy.argtypes = [C.c_void_p]
+        L.fjo_energy.restype = C.c_int64
         L.fjo_step_sf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                   C.POINTER(Trace)]
         for name in ("fjo_step_time", "fjo_step_count", "fjo_makespan", "fjo_completion_time"):
@@ -116,6 +122,12 @@ class OracleEnv(object):
         self.L.fjo_set_rng(self.h, rng_seed & (2 ** 64 - 1))
         if ddt is not None:
             self.L.fjo_set_ddt(self.h, float(ddt))
+        if variant == MO_DFJSP:
+            dyn = [np.ascontiguousarray(v, dtype=np.int32) for v in (a.power, a.idle_power, a.bk_n, np.asarray(a.bk).reshape(-1))]
+            if len(dyn[3]) == 0:
+                dyn[3] = np.zeros(2, np.int32)
+            self._keep += dyn
+            self.L.fjo_set_dynamic(self.h, *[v.ctypes.data for v in dyn])
         self.state_size = self.L.fjo_state_size(self.h)
         self.done = False
 
@@ -165,6 +177,24 @@ class OracleEnv(object):
         self.done = bool(done.value)
         self.trace = tr
         return st, rew.value, self.done
+
+    def step_dyn(self, action, reward_policy, completion=None, tardiness=None, energy=None):
+        st = np.zeros(self.state_size)
+        rew, done, tr = C.c_double(), C.c_int(), Trace()
+        rc = self.L.fjo_step_dyn(self.h, int(action[0]), int(action[1]), int(reward_policy),
+                                 0.0 if completion is None else float(completion),
+                                 0.0 if tardiness is None else float(tardiness),
+                                 0.0 if energy is None else float(energy),
+                                 st.ctypes.data, C.byref(rew), C.byref(done), C.byref(tr))
+        if rc:
+            raise RuntimeError("oracle step_dyn failed rc=%d" % rc)
+        self.done = bool(done.value)
+        self.trace = tr
+        return st, rew.value, self.done
+
+    @property
+    def energy_consumption(self):
+        return self.L.fjo_energy(self.h)
 
     def play(self, actions):
         """reset + full episode in C (timing loop). Returns (steps, reward_sum)."""
