@@ -16,6 +16,7 @@ from ._capi import check
 VARIANT_SO_FJSSP = 0
 VARIANT_SO_SFJSP = 1
 VARIANT_MO_FJSSP_DISCRETES = 2
+VARIANT_MO_DFJSP = 4
 
 ST_BAD_TASK_RULE = 1
 ST_BAD_MACHINE_RULE = 2
@@ -82,7 +83,8 @@ class EnvBatch(object):
     def step(self, actions, autoreset=False, state_out=None, reward_out=None, done_out=None, mo=None):
         """step(action): SO_FJSSP.py:168-265.  actions: uint8[N, 2] device tensor.  For the MO variant
         actions[:, 0] is the flat action and `mo` (f64[N, 4] = w0, w1, completion, tardiness; <= 0 = None)
-        carries step()'s extra arguments (MO_FJSSP_discretes.py:88)."""
+        carries step()'s extra arguments (MO_FJSSP_discretes.py:88); for MO_DFJSP `mo` is f64[N, 4] =
+        reward_policy, completion, tardiness, energy_consumption (MO_DFJSP_breakdown.py:189)."""
         if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         state_out = self.state if state_out is None else state_out
@@ -115,6 +117,9 @@ class EnvBatch(object):
         check(self._lib.fjsp_env_read(self._h, _ptr(out["delay_time_sum"]), _ptr(out["makespan"]),
                                       _ptr(out["completion_time"]), _ptr(out["step_time"]), _ptr(out["step_count"]),
                                       _ptr(out["done"]), _ptr(out["status"]), self._stream()))
+        if self.variant == VARIANT_MO_DFJSP:
+            out["energy_consumption"] = torch.zeros(self.N, dtype=torch.int64, device=self.device)
+            check(self._lib.fjsp_env_energy(self._h, _ptr(out["energy_consumption"]), self._stream()))
         return out
 
     def machine_time_end(self):

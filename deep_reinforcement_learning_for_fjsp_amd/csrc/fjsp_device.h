@@ -50,6 +50,13 @@ struct EnvScalars {
 };
 static_assert(sizeof(EnvScalars) == 18 * 8, "EnvScalars must be 18 words");
 
+// MO_DFJSP extras of the env record (Layout::e_dyn)
+struct DynScalars {
+    int64_t energy;          // self.energy_consumption                 (MO_DFJSP_breakdown.py:40,253-256)
+    int64_t energy_last;     // self.energy_consumption_last            (:41)
+    double obs_hi[6];        // observation_state[10..14] (EnvScalars::obs_prev holds [0..9])
+};
+
 struct InstHeader { int32_t K, M, R, njobs; };
 
 // byte offsets inside the two record types
@@ -73,6 +80,11 @@ struct Layout {
     uint32_t i_ss;      // f64[8]   static state (MO variant); [7] = fluid_completed_time of the reset-time LP
     uint32_t i_oarr;    // i32[SP]  time_arrive_s_dict                                   (multi-order batches)
     uint32_t i_ocnt;    // u16[SP][RP] count_sr_dict                                     (multi-order batches)
+    // MO_DFJSP batches only (MO_DFJSP_instance_read.py:56-93)
+    uint32_t i_pw;      // u16[KP][MP] power_mrj_dict (op-major like i_p)
+    uint32_t i_ipw;     // i32[MP]  power_m_dict (idle power)
+    uint32_t i_bkoff;   // u16[MP+1] first breakdown window of machine m in i_bk
+    uint32_t i_bk;      // i32[BP][2] breakdown windows (start, end), machine-major, file order
     // env record: EnvScalars at 0
     uint32_t e_stride;
     uint32_t e_tend;    // i32[MP]  machine.time_end
@@ -86,6 +98,7 @@ struct Layout {
     uint32_t e_tsum;    // f64[KP]
     uint32_t e_col;     // f64[KP][MP][2]
     uint32_t e_xin;     // f64[KP][MP] fluid solution of the pending LP, written by the host service
+    uint32_t e_dyn;     // MO_DFJSP batches only: DynScalars, then i32[MP] time_end of the machine's last task (-1 = none)
     uint32_t e_lpq;     // u16[2][KP] LP inputs of the pending arrival: Q[k], n_now[k]; then i16[2] stashed (k, m) of the step
 };
 
@@ -117,7 +130,7 @@ size_t rollout_lds_bytes(const DevBatch &b);
 int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st);
 // multi-order: resume the envs whose pending LP has been solved (x in e_xin)
-int launch_arrival(const DevBatch &b, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
+int launch_arrival(const DevBatch &b, const double *mo, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
                    hipStream_t st);
 int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
                 int32_t *step_count, uint8_t *done, uint32_t *status, hipStream_t st);

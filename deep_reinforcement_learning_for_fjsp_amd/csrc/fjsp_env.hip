@@ -83,15 +83,33 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     if (!s || !out || first < 0 || n_inst <= 0 || n_envs <= 0 || (size_t)first + (size_t)n_inst > s->v.size()) {
         set_error("fjsp_env_create: bad arguments"); return FJSP_E_ARG;
     }
-    if (variant != FJSP_VARIANT_SO_FJSSP && variant != FJSP_VARIANT_SO_SFJSP && variant != FJSP_VARIANT_MO_FJSSP_DISCRETES) {
+    const bool dyn = variant == FJSP_VARIANT_MO_DFJSP;
+    if (variant != FJSP_VARIANT_SO_FJSSP && variant != FJSP_VARIANT_SO_SFJSP && variant != FJSP_VARIANT_MO_FJSSP_DISCRETES && !dyn) {
         set_error("fjsp_env_create: unknown variant"); return FJSP_E_ARG;
     }
-    int Kmax = 0, Mmax = 0, Jmax = 0, Smax = 1, Rmax = 0;
+    int Kmax = 0, Mmax = 0, Jmax = 0, Smax = 1, Rmax = 0, Bmax = 1;
     for (int i = 0; i < n_inst; ++i) {
         const Instance &in = s->v[(size_t)first + i];
         if (!in.valid) { set_error("fjsp_env_create: instance not populated"); return FJSP_E_STATE; }
         if (!in.has_x) { set_error("fjsp_env_create: fluid solution missing (call fjsp_instances_solve_fluid)"); return FJSP_E_STATE; }
-        if (in.S != 1 && variant != FJSP_VARIANT_SO_FJSSP) { set_error("only SO_FJSSP handles order arrivals (the subclasses are single-order, SO_SFJSP.py:20 / MO_FJSSP_discretes.py:21)"); return FJSP_E_UNSUPPORTED; }
+        if (dyn) {
+            if (!in.has_dynamic) { set_error("MO_DFJSP needs machine data (machine_data.csv / fjsp_instances_set_dynamic)"); return FJSP_E_STATE; }
+            int nb = 0;
+            for (int m = 0; m < in.M; ++m) {
+                nb += in.bk_n[m];
+                bool any = false;
+                for (int k = 0; k < in.K; ++k) any = any || in.p[(size_t)k * in.M + m] > 0;
+                // Machine.gap_ave divides by len(kind_task_tuple) with no epsilon (class_MODFJSP.py:158-159)
+                if (!any) { set_error("MO_DFJSP: a machine with no eligible operation (ZeroDivisionError in the reference)"); return FJSP_E_UNSUPPORTED; }
+            }
+            if (nb > 65535) { set_error("more than 65535 breakdown windows"); return FJSP_E_UNSUPPORTED; }
+            Bmax = std::max(Bmax, nb);
+            for (size_t q = 0; q < in.p.size(); ++q) {
+                if (in.power[q] < 0 || in.power[q] > 65535) { set_error("power above 65535"); return FJSP_E_UNSUPPORTED; }
+                if ((long long)in.power[q] * in.p[q] > 0x7fffffffLL) { set_error("energy of one operation above 2^31"); return FJSP_E_UNSUPPORTED; }
+            }
+        }
+        if (in.S != 1 && variant != FJSP_VARIANT_SO_FJSSP && !dyn) { set_error("only SO_FJSSP handles order arrivals (the subclasses are single-order, SO_SFJSP.py:20 / MO_FJSSP_discretes.py:21)"); return FJSP_E_UNSUPPORTED; }
         if (in.S > 64) { set_error("more than 64 orders"); return FJSP_E_UNSUPPORTED; }
         Smax = std::max(Smax, in.S); Rmax = std::max(Rmax, in.R);
         if (in.K > kWave * kMaxKC) { set_error("more than 256 operation types"); return FJSP_E_UNSUPPORTED; }
@@ -127,11 +145,11 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.MP = Mmax;
     b.JP = ((Jmax + 63) / 64) * 64;
     b.variant = variant;
-    b.n_obs = variant == FJSP_VARIANT_SO_FJSSP ? 10 : 9;
+    b.n_obs = variant == FJSP_VARIANT_SO_FJSSP ? 10 : (dyn ? 15 : 9);
     b.n_static = variant == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 7 : 0;
     b.state_size = b.n_static + 2 * b.n_obs;
     b.rng_seed = rng_seed;
-    b.mord = Smax > 1 ? 1 : 0; b.SP = Smax; b.RP = Rmax;
+    b.mord = (Smax > 1 || dyn) ? 1 : 0; b.SP = Smax; b.RP = Rmax;     // MO_DFJSP always runs on the per-env fluid tables
     e->src = s; e->first = first;
     const size_t KP = (size_t)b.KP, MP = (size_t)b.MP, JP = (size_t)b.JP, NI = (size_t)n_inst, N = (size_t)n_envs;
     // ---- record layouts (fjsp_device.h)
@@ -145,6 +163,10 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         L.i_x = take(MP * KP * 8, 8); L.i_col = take(MP * KP * 16, 16);
         L.i_ss = take(64, 8);
         L.i_oarr = take((size_t)Smax * 4, 4); L.i_ocnt = take((size_t)Smax * Rmax * 2, 4);
+        if (dyn) {
+            L.i_pw = take(MP * KP * 2, 4); L.i_ipw = take(MP * 4, 4); L.i_bkoff = take((MP + 1) * 2, 4);
+            L.i_bk = take((size_t)Bmax * 8, 8);
+        }
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(MP * KP * 8, 8);
@@ -152,6 +174,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             L.e_q0 = take(KP * 4, 4); L.e_fmask = take(KP * 4, 4); L.e_rsum = take(KP * 8, 8); L.e_tsum = take(KP * 8, 8);
             L.e_col = take(MP * KP * 16, 16); L.e_xin = take(MP * KP * 8, 8); L.e_lpq = take(KP * 4 + 8, 4);
         }
+        if (dyn) L.e_dyn = take(sizeof(DynScalars) + MP * 4, 8);
         L.e_stride = (uint32_t)((o + 255) / 256 * 256);
     }
     std::vector<unsigned char> islab(NI * L.i_stride, 0);
@@ -186,7 +209,8 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
                 const int c_s = in.count[(size_t)so * in.R + r];
                 const long r_due = py_round((double)((long)in.delivery[so] * in.Jr[r]) / (double)c_s);
                 for (int n = cnt; n < cnt + c_s; ++n) {
-                    due[jbeg + n] = (int32_t)py_round((double)(r_due * n) / (double)c_s);
+                    due[jbeg + n] = dyn ? in.delivery[so]                                 // class_MODFJSP.py:224
+                                        : (int32_t)py_round((double)(r_due * n) / (double)c_s);
                     jinfo[jbeg + n] = (uint32_t)in.koff[r] | ((uint32_t)in.Jr[r] << 16);
                 }
                 cnt += c_s;
@@ -209,6 +233,22 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
                 first4[k] = f4;
             }
             jbeg += cnt;
+        }
+        if (dyn) {
+            uint16_t *pw = reinterpret_cast<uint16_t *>(ip(i, L.i_pw));
+            int32_t *ipw = reinterpret_cast<int32_t *>(ip(i, L.i_ipw));
+            uint16_t *bko = reinterpret_cast<uint16_t *>(ip(i, L.i_bkoff));
+            int32_t *bk = reinterpret_cast<int32_t *>(ip(i, L.i_bk));
+            for (int k = 0; k < in.K; ++k)
+                for (int m = 0; m < in.M; ++m) pw[(size_t)k * MP + m] = (uint16_t)in.power[(size_t)k * in.M + m];
+            int off = 0;
+            for (int m = 0; m < (int)MP; ++m) {
+                bko[m] = (uint16_t)off;
+                if (m < in.M) { ipw[m] = in.idle_power[m]; off += in.bk_n[m]; }
+            }
+            bko[MP] = (uint16_t)off;
+            for (int q = 0; q < 2 * off; ++q) bk[q] = in.bk[(size_t)q];
+            reinterpret_cast<double *>(ip(i, L.i_ss))[0] = in.ddt;                         // observation[0] = self.DDT
         }
         if (variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) {
             // MO_FJSSP_discretes.py:55-64 static_state_extract
@@ -247,6 +287,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         //   column gather at k_sel (p u16, un/arr/rate f64) + un write                      M * 26 + 8
         //   actions in, state/reward/done out                                               2 + S*8 + 8 + 1
         bytes_acc += in.K * 36.0 + nj * 16.0 + in.M * 16.0 + 304.0 + in.M * 26.0 + 8.0 + 2.0 + b.state_size * 8.0 + 9.0;
+        if (dyn) bytes_acc += in.M * 14.0 + 2.0 * sizeof(DynScalars);    // power column, idle power, last-task ends r/w, DynScalars r/w
     }
     e->step_bytes = (int64_t)(bytes_acc / (double)NI + 0.5);
 
@@ -304,7 +345,7 @@ namespace {
 // Multi-order batches: after a step launch, solve the fluid LP of every env that stopped at an order
 // arrival (class_FJSSP.py:239 on the live state) with the host simplex and let arrival_kernel finish
 // those steps.  Synchronises the stream: order arrivals make step() blocking for such batches.
-int service_arrivals(fjsp_env *e, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace, hipStream_t st) {
+int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace, hipStream_t st) {
     const DevBatch &b = e->b;
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, b.pending_count, 4, hipMemcpyDeviceToHost, st));
@@ -331,7 +372,7 @@ int service_arrivals(fjsp_env *e, double *d_state, double *d_reward, uint8_t *d_
             for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
         HIP_TRY(hipMemcpy(rec + b.L.e_xin, xin.data(), KP * MP * 8, hipMemcpyHostToDevice));
     }
-    if (launch_arrival(b, (int)n, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
+    if (launch_arrival(b, d_mo, (int)n, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
     HIP_TRY(hipMemsetAsync(b.pending_count, 0, 4, st));
     return FJSP_OK;
 }
@@ -351,7 +392,7 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
     if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
     }
-    if (e->b.mord) return service_arrivals(e, d_state, d_reward, d_done, nullptr, (hipStream_t)stream);
+    if (e->b.mord) return service_arrivals(e, d_mo, d_state, d_reward, d_done, nullptr, (hipStream_t)stream);
     return FJSP_OK;
 }
 
@@ -374,7 +415,7 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, 
             set_error("step_kernel launch failed"); return FJSP_E_HIP;
         }
         if (e->b.mord) {
-            const int rc = service_arrivals(e, d_state_last, d_reward ? d_reward + (size_t)s2 * N : nullptr, e->d_done_scratch,
+            const int rc = service_arrivals(e, d_mo, d_state_last, d_reward ? d_reward + (size_t)s2 * N : nullptr, e->d_done_scratch,
                                             d_trace_km ? d_trace_km + (size_t)s2 * N * 2 : nullptr, st);
             if (rc != FJSP_OK) return rc;
         }
@@ -396,6 +437,15 @@ int fjsp_env_machine_time_end(fjsp_env *e, int32_t *d_tend, int32_t m_stride, vo
     DeviceGuard guard(e->device);
     HIP_TRY(hipMemcpy2DAsync(d_tend, (size_t)m_stride * 4, e->b.envs + e->b.L.e_tend, (size_t)e->b.L.e_stride,
                              (size_t)e->b.MP * 4, (size_t)e->b.N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FJSP_OK;
+}
+
+int fjsp_env_energy(fjsp_env *e, int64_t *d_energy, void *stream) {
+    if (!e || !d_energy) { set_error("fjsp_env_energy: null argument"); return FJSP_E_ARG; }
+    if (e->b.variant != FJSP_VARIANT_MO_DFJSP) { set_error("fjsp_env_energy: not a MO_DFJSP batch"); return FJSP_E_STATE; }
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipMemcpy2DAsync(d_energy, 8, e->b.envs + e->b.L.e_dyn, (size_t)e->b.L.e_stride, 8, (size_t)e->b.N,
+                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FJSP_OK;
 }
 

@@ -45,8 +45,12 @@ namespace fjsp {
 // LP mid-episode, SO_FJSSP.py:218-231).  Its fluid tables live in the env record and its step can stop at
 // an arrival and be finished by arrival_kernel once the host has solved the LP.
 constexpr int kMord = 3;
+// MO_DFJSP_breakdown.py: the multi-order skeleton plus breakdown windows, energy, 12 x 10 rules, 15 observations.
+constexpr int kDyn = FJSP_VARIANT_MO_DFJSP;
 template <int V>
 constexpr bool is_so_v = (V == FJSP_VARIANT_SO_FJSSP || V == kMord);
+template <int V>
+constexpr bool is_mord_v = (V == kMord || V == kDyn);
 constexpr uint32_t kAbsent = 0xFFu;      // next_stage of a job whose order has not arrived yet
 
 // ------------------------------------------------------------------ diagnostics
@@ -166,7 +170,7 @@ struct W {
     // batch constants copied out of the kernel argument (keeping a pointer to the argument struct
     // makes the compiler spill it to scratch and re-load fields through memory)
     int KP, MP, JP, n_obs, n_static, state_size;
-    uint32_t e_jst, e_tend, e_mjob, e_un;
+    uint32_t e_jst, e_tend, e_mjob, e_un, e_dyn;
     const double *sstate;
     double fluid_completed_time;
     int env, inst, lane;
@@ -179,6 +183,7 @@ struct W {
     long long tard_done, delay_sum;
     uint64_t env_seed;
     int t_arr, next_order, pending, n_orders;      // order arrivals (multi-order batches)
+    long long energy, energy_last;                 // MO_DFJSP: energy_consumption(_last)
     const unsigned char *ir;
     // lane = operation type
     uint32_t kA[KC], kB[KC], elig[KC], fmask[KC], first4[KC];
@@ -188,7 +193,8 @@ struct W {
     double max_e[KC], sum_e[KC];
     // lane = machine
     int tend_m, mjob_m;
-    // lane i < 10: previous observation
+    int tlast_m, ipw_m;      // MO_DFJSP: time_end of the machine's last task (-1 = none), idle power
+    // lane i < n_obs: previous observation
     double obs_prev_l;
     // wave-private LDS
     uint32_t *jstL;
@@ -199,6 +205,7 @@ struct W {
     // rows of this instance / env record
     // op-major matrices of the instance record: p_i[k*MP+m]; col_i[(k*MP+m)*2 + {0: arrival, 1: rate}]
     const uint16_t *p_i;
+    const uint16_t *pw_i;    // MO_DFJSP: power_mrj_dict, same layout as p_i
     const double *col_i;
     unsigned char *er;
     STAMP_FIELDS
@@ -216,7 +223,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
                                          bool load_state) {
     w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
-    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un;
+    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = env % b->n_inst;
@@ -242,7 +249,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         w.kB[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kB)[k];
         w.elig[c] = reinterpret_cast<const uint32_t *>(ir + L.i_elig)[k];
         w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
-        if (V == kMord && load_state) {      // tables of the last LP of THIS environment
+        if (is_mord_v<V> && load_state) {      // tables of the last LP of THIS environment
             w.fmask[c] = reinterpret_cast<const uint32_t *>(er + L.e_fmask)[k];
             w.rate_sum[c] = reinterpret_cast<const double *>(er + L.e_rsum)[k];
             w.time_sum[c] = reinterpret_cast<const double *>(er + L.e_tsum)[k];
@@ -256,8 +263,10 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     }
     const int32_t due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
     uint32_t jst0 = 0;
-    int tend0 = 0, mjob0 = -1;
+    int tend0 = 0, mjob0 = -1, tlast0 = -1, ipw0 = 0;
     double obs0 = 0.0;
+    long long en0 = 0, enl0 = 0;
+    if (V == kDyn && w.lane < MP) ipw0 = reinterpret_cast<const int32_t *>(ir + L.i_ipw)[w.lane];
     EnvScalars sc;      // uniform address: the compiler fetches it with scalar loads, no cross-lane traffic
     if (load_state) {
         jst0 = reinterpret_cast<const uint32_t *>(er + L.e_jst)[w.lane];
@@ -272,9 +281,16 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
             tend0 = reinterpret_cast<const int32_t *>(er + L.e_tend)[w.lane];
             mjob0 = reinterpret_cast<const int32_t *>(er + L.e_mjob)[w.lane];
         }
+        if (V == kDyn) {
+            const DynScalars *ds = reinterpret_cast<const DynScalars *>(er + L.e_dyn);
+            en0 = ds->energy; enl0 = ds->energy_last;
+            if (w.lane >= 10 && w.lane < 15) obs0 = ds->obs_hi[w.lane - 10];
+            if (w.lane < MP) tlast0 = reinterpret_cast<const int32_t *>(er + L.e_dyn + sizeof(DynScalars))[w.lane];
+        }
     }
     w.p_i = reinterpret_cast<const uint16_t *>(ir + L.i_p);
-    w.col_i = reinterpret_cast<const double *>(V == kMord ? er + L.e_col : ir + L.i_col);
+    w.pw_i = reinterpret_cast<const uint16_t *>(ir + (V == kDyn ? L.i_pw : L.i_p));
+    w.col_i = reinterpret_cast<const double *>(is_mord_v<V> ? er + L.e_col : ir + L.i_col);
     w.ir = ir;
     w.t_arr = 0; w.next_order = 1; w.pending = 0;
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
@@ -282,13 +298,14 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.fluid_completed_time = w.sstate[7];
     // ---- consume
     w.K = uni(h.K); w.M = uni(h.M); w.njobs = uni(h.njobs);
-    w.n_orders = V == kMord ? uni(h.R >> 16) : 1;       // InstHeader.R carries S in its high half for multi-order batches
+    w.n_orders = is_mord_v<V> ? uni(h.R >> 16) : 1;       // InstHeader.R carries S in its high half for multi-order batches
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         w.tot[c] = (int)(w.kA[c] >> 16);
-        if (!(V == kMord && load_state)) w.q0[c] = w.tot[c];
+        if (!(is_mord_v<V> && load_state)) w.q0[c] = w.tot[c];
     }
     w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
+    w.ipw_m = ipw0; w.tlast_m = -1; w.energy = 0; w.energy_last = 0;
     w.dueL[w.lane] = due0;
     for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
     if (!load_state) return;
@@ -302,6 +319,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.obs_prev_l = obs0;
     w.tend_m = w.lane < w.M ? tend0 : 0;
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
+    if (V == kDyn) { w.tlast_m = w.lane < w.M ? tlast0 : -1; w.energy = en0; w.energy_last = enl0; }
     if (un_lds) {
         const double *src = reinterpret_cast<const double *>(er + L.e_un);
         for (int i = w.lane; i < w.K * MP; i += kWave) w.unp[i] = src[i];
@@ -311,7 +329,6 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
 
 template <int KC, int V>
 __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
-    const int KP = w.KP;
     unsigned char *er = w.er;
     wave_sync();
     if (w.lane == 0) {
@@ -326,6 +343,12 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
     if (w.lane < w.M) {
         reinterpret_cast<int32_t *>(er + w.e_tend)[w.lane] = w.tend_m;
         reinterpret_cast<int32_t *>(er + w.e_mjob)[w.lane] = w.mjob_m;
+    }
+    if (V == kDyn) {
+        DynScalars *ds = reinterpret_cast<DynScalars *>(er + w.e_dyn);
+        if (w.lane == 0) { ds->energy = w.energy; ds->energy_last = w.energy_last; }
+        if (w.lane >= 10 && w.lane < 15) ds->obs_hi[w.lane - 10] = w.obs_prev_l;
+        if (w.lane < w.M) reinterpret_cast<int32_t *>(er + w.e_dyn + sizeof(DynScalars))[w.lane] = w.tlast_m;
     }
     for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + w.e_jst)[n] = w.jstL[n];
     if (un_lds) {
@@ -357,7 +380,7 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
             const uint32_t js = w.jstL[n];
             const int d = w.dueL[n];            // fetched together with the state word: one LDS latency, not two
             const int nj = (int)(js & 0xFFu);
-            if (V == kMord && nj != (int)kAbsent) arrived++;
+            if (is_mord_v<V> && nj != (int)kAbsent) arrived++;
             if (nj <= j) {
                 const int da = t - d;                                   // :138
                 const double est = td + ts * (double)(idx + 1);        // :136,139
@@ -379,7 +402,7 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
         w.nun[c] = idx; w.cnt_a[c] = cnt_a; w.cnt_e[c] = cnt_e; w.max_a[c] = max_a; w.max_e[c] = max_e;
         w.fifo_cnt[c] = fifo; w.head_job[c] = head; w.due_min[c] = dmin; w.tard[c] = tard;
         w.sum_e[c] = sum_e;                                             // :153 urgency = sum_e / nun, formed on demand
-        if (V == kMord) w.tot[c] = arrived;
+        if (is_mord_v<V>) w.tot[c] = arrived;
     }
 }
 
@@ -455,7 +478,7 @@ __device__ __forceinline__ bool any_available(const W<KC, V> &w, uint32_t idle) 
 // gap_time = step_time - order_arrive_time (SO_FJSSP.py:237); order_arrive_time is 0 with a single order
 template <int KC, int V>
 __device__ __forceinline__ double fluid_dt(const W<KC, V> &w) {
-    return (double)(V == kMord ? w.t - w.t_arr : w.t);
+    return (double)(is_mord_v<V> ? w.t - w.t_arr : w.t);
 }
 // fluid_unprocessed_number (SO_FJSSP.py:239-240) is a pure function of the clock: Q0 - rate_sum * gap_time
 template <int KC, int V>
@@ -499,6 +522,31 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
             return fluid ? argext_i32<KC, false>(fav, tmin) : argext_i32<KC, false>(av, tmin);
         }
         if (a0 == 3) return nth_bit<KC>(av, rng_choice(w, popc_masks<KC>(av)));   // rule 4
+        w.status |= FJSP_ST_BAD_TASK_RULE;
+        return -1;
+    }
+    if (V == kDyn && a0 >= 5) {                       // MO_DFJSP_breakdown.py:357-381, rules 6..12
+        if (a0 == 5) return argext_i32<KC, false>(av, w.due_min);               // rule 6: argmin due date over available
+        if (a0 <= 9) {                                // rules 7/8: argmin energy_min[_fluid]_rj, 9/10: argmin time_min[_fluid]_rj
+            const bool energy = a0 <= 7;
+            const bool fluid = (a0 == 6 || a0 == 8) && anyfav;
+            int vmin[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const uint32_t cand = idle & (fluid ? w.fmask[c] : w.elig[c]);
+                int best = 0x7fffffff;
+                for (int m = 0; m < w.M; ++m) {
+                    const int o = (c * kWave + w.lane) * w.MP + m;
+                    const int pv = w.p_i[o];
+                    const int v = energy ? pv * (int)w.pw_i[o] : pv;             // energy_mrj_dict class_MODFJSP.py:178
+                    if (((cand >> m) & 1u) && v < best) best = v;
+                }
+                vmin[c] = best;
+            }
+            return fluid ? argext_i32<KC, false>(fav, vmin) : argext_i32<KC, false>(av, vmin);
+        }
+        if (a0 == 10 && anyfav) return nth_bit<KC>(fav, rng_choice(w, popc_masks<KC>(fav)));   // rule 11
+        if (a0 == 10 || a0 == 11) return nth_bit<KC>(av, rng_choice(w, popc_masks<KC>(av)));   // rules 11, 12
         w.status |= FJSP_ST_BAD_TASK_RULE;
         return -1;
     }
@@ -546,7 +594,6 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
 // kind_task_tuple order of unprocessed - fluid_unprocessed, divided by (n + 1e-18).
 template <int KC, int V>
 __device__ __forceinline__ double machine_gap_ave(const W<KC, V> &w, int m) {
-    const int KP = w.KP;
     const double dt = fluid_dt(w);
     double s = 0.0;
     int n = 0;
@@ -565,14 +612,15 @@ __device__ __forceinline__ double machine_gap_ave(const W<KC, V> &w, int m) {
             s = s + rld(g, l);
         }
     }
+    if (V == kDyn) return s / (double)n;             // class_MODFJSP.py:158-159 has no epsilon
     return s / ((double)n + 1e-18);
 }
 
 // SO_FJSSP.py:300-322 machine_select.  Candidate lists are visited in CPython's
 // list(set & set) order (fjsp_pyset.h): ascending for M <= 8, not always beyond.
 template <int KC, int V>
-__device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel) {
-    const int KP = w.KP;
+__device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel,
+                                              int *en_sel) {
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const uint32_t elig_s = rlu(pick<KC>(w.elig, cs), ls), fm_s = rlu(pick<KC>(w.fmask, cs), ls);
     const uint32_t first4 = rlu(pick<KC>(w.first4, cs), ls);
@@ -581,7 +629,7 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
     if (sel.n == 0) { w.status |= FJSP_ST_NO_EVENT; return -1; }
     // lane m: gap_rj_dict[m][k_sel] (class_FJSSP.py:137-142) and p[m][k_sel]
     double g = 0.0, un = 0.0;
-    int pm = 0;
+    int pm = 0, en = 0;
     if (w.lane < w.M && ((sel.mask >> w.lane) & 1u)) {
         // op-major layout: the column of k_sel is MP contiguous entries per array (a handful of cache lines)
         const int o = k_sel * w.MP + w.lane;
@@ -592,6 +640,7 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         un = w.unp[o];
         const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
         g = un - (ar.x - fluid_dt(w) * ar.y);
+        if (V == kDyn) en = pm * (int)w.pw_i[o];                 // energy_mrj_dict class_MODFJSP.py:178
 #endif
     }
     auto visit = [&](const CandList &l, auto &&f) {
@@ -614,8 +663,30 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         visit(l, [&](int m) { const double v = machine_gap_ave<KC, V>(w, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
+    auto argmin_lane = [&](const CandList &l, int key) {          // first minimum of a machine-lane integer
+        int best = -1, bv = 0;
+        visit(l, [&](int m) { const int v = rl(key, m); if (best < 0 || v < bv) { bv = v; best = m; } });
+        return best;
+    };
     int m_sel;
-    if (V == FJSP_VARIANT_SO_SFJSP) {
+    if (V == kDyn) {
+        const CandList &fl = fsel.n ? fsel : sel;
+        switch (a1) {                                             // MO_DFJSP_breakdown.py:384-428
+        case 0: m_sel = argmax_gap(fl); break;
+        case 1: m_sel = argmin_p(fl); break;
+        case 2: m_sel = argmin_p(sel); break;
+        case 3: m_sel = argmax_gave(fl); break;
+        case 4: m_sel = argmin_lane(fl, en); break;               // rule 5: least processing energy, fluid first
+        case 5: m_sel = argmin_lane(sel, en); break;
+        case 6: m_sel = argmin_lane(fl, w.ipw_m); break;          // rule 7: least idle power, fluid first
+        case 7: m_sel = argmin_lane(sel, w.ipw_m); break;
+        case 8: m_sel = cand_at(fl, rng_choice(w, fl.n)); break;
+        case 9: m_sel = cand_at(sel, rng_choice(w, sel.n)); break;
+        default:
+            w.status |= FJSP_ST_BAD_MACHINE_RULE;
+            return -1;
+        }
+    } else if (V == FJSP_VARIANT_SO_SFJSP) {
         switch (a1) {                                             // SO_SFJSP.py:190-214
         case 0: m_sel = argmax_gap(fsel.n ? fsel : sel); break;
         case 1: m_sel = argmin_p(fsel.n ? fsel : sel); break;
@@ -649,6 +720,7 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
     }
     *p_sel = rl(pm, m_sel);
     *un_sel = rld(un, m_sel);
+    if (V == kDyn) *en_sel = rl(en, m_sel);
     return m_sel;
 }
 
@@ -701,13 +773,32 @@ __device__ __forceinline__ int order_arrive(W<KC, V> &w, const DevBatch *b, int 
 // the clock until some operation type is available again (or the episode ends).
 template <int KC, int V>
 __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch *b, int k_sel, int m_sel, int pm,
-                                                     double un_sel) {
-    const int KP = w.KP;
+                                                     double un_sel, int en_sel) {
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const int job = rl(pick<KC>(w.head_job, cs), ls);                       // :176 job_now_list[0]
     const uint32_t kb = rlu(pick<KC>(w.kB, cs), ls);
     const int Jr = (int)((kb >> 8) & 0xFFu);
-    const int time_end = w.t + pm;                                           // :184
+    int time_end = w.t + pm;                                                 // :184
+    int machine_end = time_end;
+    if (V == kDyn) {
+        // MO_DFJSP_breakdown.py:204-231: the windows of m_sel in file order; a window that covers the start or
+        // begins inside the task stretches the task, one that begins exactly at its end only delays the machine
+        const uint16_t *bko = reinterpret_cast<const uint16_t *>(w.ir + b->L.i_bkoff);
+        const int32_t *bk = reinterpret_cast<const int32_t *>(w.ir + b->L.i_bk);
+        const int q1 = bko[m_sel + 1];
+        for (int q = bko[m_sel]; q < q1; ++q) {
+            const int bs = bk[2 * q], be = bk[2 * q + 1];
+            if (bs <= w.t && w.t < be) { time_end += be - w.t; machine_end = time_end; }
+            else if (w.t < bs && bs < time_end) { time_end += be - bs; machine_end = time_end; }
+            else if (bs == time_end) machine_end += be - bs;
+            else if (bs > time_end) break;
+        }
+        // :253-256 processing energy, then the idle energy since the machine's previous task ended
+        w.energy += (long long)en_sel;
+        const int tl = rl(w.tlast_m, m_sel);
+        if (tl >= 0) w.energy += (long long)(w.t - tl) * (long long)rl(w.ipw_m, m_sel);
+        if (w.lane == m_sel) w.tlast_m = time_end;
+    }
     const int nj = (int)(kb & 0xFFu) + 1;       // the FIFO head of (r, j) is at stage j; it moves to j + 1
     if (w.lane == 0) {
         w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);                        // :186-191
@@ -718,7 +809,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
         if (c == cs && w.lane == ls) w.fifo_cnt[c]--;
     // machine lane: time_end, and job | (k of the job's next stage + 1) << 16 so that the release at the
     // completion event (:209-215) needs no look-up (0 in the high half = the job has no further stage)
-    if (w.lane == m_sel) { w.tend_m = time_end; w.mjob_m = job | ((nj == Jr ? 0 : k_sel + 2) << 16); }   // :194-197
+    if (w.lane == m_sel) { w.tend_m = machine_end; w.mjob_m = job | ((nj == Jr ? 0 : k_sel + 2) << 16); }   // :194-197
     w.busy |= 1u << m_sel;
     if (time_end > w.completion) w.completion = time_end;
     if (nj == Jr) {                                                          // :200-202
@@ -747,7 +838,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
                     if (c == (kk >> 6) && w.lane == (kk & 63)) w.fifo_cnt[c]++;
             }
         }
-        if (V == kMord && w.next_order < w.n_orders) {                       // :218-231 order arrival
+        if (is_mord_v<V> && w.next_order < w.n_orders) {                     // :218-231 order arrival
             const int t_next = reinterpret_cast<const int32_t *>(w.ir + b->L.i_oarr)[w.next_order];
             const bool due_now = t_next <= w.t, idle_jump = !due_now && w.n_unassigned == 0;
             if (due_now || idle_jump) {
@@ -760,7 +851,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
         }
         w.busy &= ~(uint32_t)__ballot(w.lane < w.M && w.tend_m <= w.t);     // :233-235
         idle = ~w.busy & w.mmask;
-        if (w.n_unassigned == 0 && !(V == kMord && w.next_order < w.n_orders)) { w.done = 1; break; }   // :247-250
+        if (w.n_unassigned == 0 && !(is_mord_v<V> && w.next_order < w.n_orders)) { w.done = 1; break; }   // :247-250
     }
     wave_sync();
 }
@@ -806,7 +897,7 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
     double frv[KC], grv[KC];
     bool single_job = true;      // every operation type has exactly one job: the divisions below are x / 1.0 == x
 #pragma unroll
-    for (int c = 0; c < KC; ++c) single_job = single_job && V != kMord && __ballot((w.kA[c] >> 16) > 1u) == 0;
+    for (int c = 0; c < KC; ++c) single_job = single_job && !is_mord_v<V> && __ballot((w.kA[c] >> 16) > 1u) == 0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int tot = w.tot[c];
@@ -836,7 +927,9 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
     wave_sync();
     const double sd = sqrt(lds_chain_sum(src_off, n8) / len);
     const double cro_ave = ave_fr, cro_std = rld(sd, 0), gap_ave = ave_gr, gap_std = rld(sd, 1), ct_std = rld(sd, 2);
-    if (V == FJSP_VARIANT_SO_SFJSP) {
+    if (V == FJSP_VARIANT_SO_SFJSP || V == kDyn) {
+        // MO_DFJSP_breakdown.py:94-118: [DDT, M, S, ct_std, ratio_idle, cro_ave, cro_std, gap_ave, gap_std, gap_m_ave,
+        //                                gap_m_std, dro_a, dro_e, drj_a, drj_e]
         // SO_SFJSP.py:64-83: [M_idle_ratio, ct_std, cro_ave, cro_std, ratio_idle, gap_ave, gap_std, gap_m_ave, gap_m_std]
         const uint32_t idle = ~w.busy & w.mmask;
         int nav = 0, nfav = 0;
@@ -853,7 +946,6 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         // 0..2 walk one row each.  In the step kernel the unprocessed matrix lives in HBM and lane 0 has just
         // updated one element of it, so that store is drained first.
         wave_sync_global();
-        const int KP = w.KP;
         const double dt = fluid_dt(w);
         double gave_m = 0.0;                       // lane m (< M): gap_ave of machine m
         for (int m0 = 0; m0 < M; m0 += 3) {
@@ -881,7 +973,8 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
             wave_sync();
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const double v = rld(sm, q) / ((double)cnt_q[q] + 1e-18);
+                const double v = V == kDyn ? rld(sm, q) / (double)cnt_q[q]               // class_MODFJSP.py:158-159
+                                           : rld(sm, q) / ((double)cnt_q[q] + 1e-18);
                 if (w.lane == m0 + q) gave_m = v;
             }
         }
@@ -895,6 +988,20 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         { const double d = gave_m - gm_ave; if (w.lane < (uint32_t)w.KP) w.tdL[w.lane] = w.lane < M ? d * d : 0.0; }
         wave_sync();
         const double gm_std = sqrt(lds_chain_sum(td_off, m8) / (double)M);
+        if (V == kDyn) {
+            const int num = w.lane == 0 ? delay_a : (w.lane == 1 ? delay_e : (w.lane == 2 ? job_a : job_e));
+            const int den = w.lane < 2 ? task_number : job_number;
+            const double ratio = w.done ? 0.0 : (double)num / (double)den;       // :176-185
+            wave_sync();
+            if (w.lane == 0) {
+                w.scrL[0] = w.sstate[0]; w.scrL[1] = (double)M; w.scrL[2] = (double)w.n_orders; w.scrL[3] = ct_std;
+                w.scrL[4] = ratio_idle; w.scrL[5] = cro_ave; w.scrL[6] = cro_std; w.scrL[7] = gap_ave; w.scrL[8] = gap_std;
+                w.scrL[9] = gm_ave; w.scrL[10] = gm_std;
+            }
+            if (w.lane < 4) w.scrL[11 + w.lane] = ratio;
+            wave_sync();
+            return tard_unproc;
+        }
         if (w.lane == 0) {
             w.scrL[0] = m_idle_ratio; w.scrL[1] = ct_std; w.scrL[2] = cro_ave; w.scrL[3] = cro_std; w.scrL[4] = ratio_idle;
             w.scrL[5] = gap_ave; w.scrL[6] = gap_std; w.scrL[7] = gm_ave; w.scrL[8] = gm_std;
@@ -941,7 +1048,8 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
     w.tard_done = 0; w.delay_sum = 0;
     w.tend_m = 0; w.mjob_m = -1;
     w.t_arr = 0; w.next_order = 1; w.pending = 0;
-    if (V == kMord) {
+    w.energy = 0; w.energy_last = 0; w.tlast_m = -1;
+    if (is_mord_v<V>) {
         // per-environment copy of the reset-time fluid tables (they change at every later arrival)
         const Layout &L = b->L;
 #pragma unroll
@@ -995,15 +1103,15 @@ __device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a
     const uint32_t idle = ~w.busy & w.mmask;
     const int k_sel = task_select<KC, V>(w, a0, idle);
     STAMP(w, 2);
-    int pm = 0;
+    int pm = 0, en_sel = 0;
     double un_sel = 0.0;
-    const int m_sel = k_sel >= 0 ? machine_select<KC, V>(w, a1, k_sel, idle, &pm, &un_sel) : -1;
+    const int m_sel = k_sel >= 0 ? machine_select<KC, V>(w, a1, k_sel, idle, &pm, &un_sel, &en_sel) : -1;
     STAMP(w, 3);
     *k_out = k_sel; *m_out = m_sel;
     if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
-    dispatch_and_advance<KC, V>(w, b, k_sel, m_sel, pm, un_sel);
+    dispatch_and_advance<KC, V>(w, b, k_sel, m_sel, pm, un_sel, en_sel);
     STAMP(w, 4);
-    if (V == kMord && w.pending) return 0.0;        // an order arrived: the step is finished by arrival_kernel
+    if (is_mord_v<V> && w.pending) return 0.0;        // an order arrived: the step is finished by arrival_kernel
     return env_step_finish<KC, V>(w, mo, state_out);
 }
 
@@ -1029,6 +1137,21 @@ __device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo,
     const int dc = w.completion_last - w.completion;
     w.delay_sum = delay_new;                                                 // :263
     w.completion_last = w.completion;
+    if (V == kDyn) {                 // MO_DFJSP_breakdown.py:430-447 compute_reward(reward_policy, completion, tardiness, energy)
+        const double de = (double)(w.energy_last - w.energy);
+        w.energy_last = w.energy;
+        const double pol = mo ? mo[0] : 1.0;
+        if (pol == 0.0) return (double)dc;
+        if (pol == 1.0) return (double)(-delta);
+        if (pol == 2.0) return de;
+        if (pol == 3.0) {
+            const double cn = mo[1], tn = mo[2], en = mo[3];
+            if (tn > 0.0) return (double)dc / cn + (double)(-delta) / tn + de / en;
+            return (double)dc / cn + de / en;
+        }
+        w.status |= FJSP_ST_BAD_TASK_RULE;                                   // MyError :447
+        return 0.0;
+    }
     if (is_sf) return (double)dc / w.fluid_completed_time;                   // SO_SFJSP.py:216-220 (dc = -(C - C_last))
     if (!is_mo) return (double)(-delta);                                     // :328 (exact integer)
     // MO_FJSSP_discretes.py:232-244 compute_reward(weight_vector, completion, tardiness)
@@ -1137,7 +1260,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
 #endif
     int k_sel, m_sel;
     const double reward = env_step<KC, V>(w, &b, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
-    if (V == kMord && w.pending) {
+    if (is_mord_v<V> && w.pending) {
         // an order arrived inside this step: park the env for the host LP service (fjsp_env.hip), which
         // finishes the step with arrival_kernel; the outputs of this env are written there
         if (w.lane == 0) {
@@ -1189,10 +1312,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t 
 // Multi-order: finish the step of every env parked at an order arrival.  The host service has solved the
 // fluid LP of the env's live state (class_FJSSP.py:239) and left x in the env record; this kernel runs
 // update_fluid_parameter (:282-306) for that env, then the second half of step().
-template <int KC>
-__global__ __launch_bounds__(256, 4) void arrival_kernel(DevBatch b, int n_pending, double *state_out, double *reward_out,
-                                                         uint8_t *done_out, int16_t *trace_km) {
-    constexpr int V = kMord;
+template <int KC, int V>
+__global__ __launch_bounds__(256, 4) void arrival_kernel(DevBatch b, const double *mo, int n_pending, double *state_out,
+                                                         double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     const int wave = uni((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * (blockDim.x >> 6) + wave;
     if (idx >= n_pending) return;
@@ -1239,7 +1361,7 @@ __global__ __launch_bounds__(256, 4) void arrival_kernel(DevBatch b, int n_pendi
     }
     wave_sync_global();
     w.pending = 0;
-    const double reward = env_step_finish<KC, V>(w, nullptr, state_out);
+    const double reward = env_step_finish<KC, V>(w, mo ? mo + (size_t)env * 4 : nullptr, state_out);
     if (w.lane == 0) {
         const int16_t *stash = reinterpret_cast<const int16_t *>(w.er + L.e_lpq) + 2 * b.KP;
         if (reward_out) reward_out[env] = reward;
@@ -1290,6 +1412,7 @@ static int dispatch_kc(int kc, F &&f) {
 }
 template <class F>
 static int dispatch(const DevBatch &b, F &&f) {
+    if (b.variant == FJSP_VARIANT_MO_DFJSP) return dispatch_kc<kDyn>(b.KC, f);
     if (b.mord) return dispatch_kc<kMord>(b.KC, f);
     switch (b.variant) {
     case FJSP_VARIANT_SO_FJSSP: return dispatch_kc<FJSP_VARIANT_SO_FJSSP>(b.KC, f);
@@ -1331,16 +1454,16 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_arrival(const DevBatch &b, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
-                   hipStream_t st) {
+int launch_arrival(const DevBatch &b, const double *mo, int n_pending, double *state, double *reward, uint8_t *done,
+                   int16_t *trace_km, hipStream_t st) {
     const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
     const dim3 grid((unsigned)((n_pending + 3) / 4));
-    switch (b.KC) {
-    case 1: hipLaunchKernelGGL((arrival_kernel<1>), grid, dim3(256), lds, st, b, n_pending, state, reward, done, trace_km); break;
-    case 2: hipLaunchKernelGGL((arrival_kernel<2>), grid, dim3(256), lds, st, b, n_pending, state, reward, done, trace_km); break;
-    case 4: hipLaunchKernelGGL((arrival_kernel<4>), grid, dim3(256), lds, st, b, n_pending, state, reward, done, trace_km); break;
-    default: return -1;
-    }
+    auto go = [&](auto kc, auto v) {
+        hipLaunchKernelGGL((arrival_kernel<decltype(kc)::value, decltype(v)::value>), grid, dim3(256), lds, st, b, mo,
+                           n_pending, state, reward, done, trace_km);
+    };
+    const int rc = b.variant == FJSP_VARIANT_MO_DFJSP ? dispatch_kc<kDyn>(b.KC, go) : dispatch_kc<kMord>(b.KC, go);
+    if (rc != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,

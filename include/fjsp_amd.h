@@ -53,7 +53,11 @@ enum {
 enum {
     FJSP_VARIANT_SO_FJSSP = 0,          /* environments/SO_FJSSP.py (pair action [6,5], 20-dim state) */
     FJSP_VARIANT_SO_SFJSP = 1,          /* environments/SO_SFJSP.py (flat 20 = 4x5, 18-dim state, makespan)  */
-    FJSP_VARIANT_MO_FJSSP_DISCRETES = 2 /* environments/MO_FJSSP_discretes.py (flat 18, 25-dim state)  */
+    FJSP_VARIANT_MO_FJSSP_DISCRETES = 2,/* environments/MO_FJSSP_discretes.py (flat 18, 25-dim state)  */
+    FJSP_VARIANT_MO_DFJSP = 4           /* environments/MO_DFJSP_breakdown.py (and MO_DFJSP.py = no breakdown windows):
+                                           pair action [12,10], 30-dim state, order arrivals, machine breakdowns,
+                                           energy; needs instances with machine data (fjsp_instances_set_dynamic
+                                           or a machine_data.csv) */
 };
 
 const char *fjsp_last_error(void);
@@ -137,7 +141,7 @@ int  fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int
                      int32_t variant, int32_t device, uint64_t rng_seed, fjsp_env **out);
 void fjsp_env_destroy(fjsp_env *e);
 int  fjsp_env_num_envs(const fjsp_env *e);
-int  fjsp_env_state_size(const fjsp_env *e);   /* 20 (SO_FJSSP) / 18 (SO_SFJSP) / 25 (MO_FJSSP_discretes) */
+int  fjsp_env_state_size(const fjsp_env *e);   /* 20 (SO_FJSSP) / 18 (SO_SFJSP) / 25 (MO_FJSSP_discretes) / 30 (MO_DFJSP) */
 int  fjsp_env_device(const fjsp_env *e);
 
 /* reset(): SO_FJSSP.py:51-76.  d_mask (u8[N], nullable): reset only envs with
@@ -149,7 +153,11 @@ int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *st
  * variants (SO_SFJSP, MO_FJSSP_discretes) d_actions[..][0] is the flat action;
  * for the MO variant d_mo (f64[N][4] = w0, w1, completion,
  * tardiness; <=0 = None; nullable) carries step()'s extra arguments
- * (MO_FJSSP_discretes.py:88).  Outputs (all nullable): d_state f64[N][S],
+ * (MO_FJSSP_discretes.py:88); for FJSP_VARIANT_MO_DFJSP d_mo is f64[N][4] =
+ * reward_policy (0 makespan, 1 tardiness, 2 energy, 3 normalised sum),
+ * completion, tardiness, energy_consumption (MO_DFJSP_breakdown.py:189,430-447;
+ * NULL = policy 1; any other policy value sets FJSP_ST_BAD_TASK_RULE like the
+ * reference's MyError).  Outputs (all nullable): d_state f64[N][S],
  * d_reward f64[N], d_done u8[N].  Envs already done are left untouched and get
  * FJSP_ST_STEP_AFTER_DONE unless autoreset != 0, in which case a done env is
  * reset first and the step applies to the fresh episode. */
@@ -173,6 +181,8 @@ int fjsp_env_read(fjsp_env *e, int64_t *d_delay_time_sum, int32_t *d_makespan, i
                   void *stream);
 /* machine_dict[m].time_end: i32[N][M_max] (SO_FJSSP.py:426). */
 int fjsp_env_machine_time_end(fjsp_env *e, int32_t *d_tend, int32_t m_stride, void *stream);
+/* energy_consumption i64[N] of a FJSP_VARIANT_MO_DFJSP batch (MO_DFJSP_breakdown.py:253-256). */
+int fjsp_env_energy(fjsp_env *e, int64_t *d_energy, void *stream);
 /* fluid tables of env i copied to host (tests): rate/arr [K*M] k-major, rate_sum/time_sum [K]. */
 int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
                           double *h_rate_sum, double *h_time_sum);

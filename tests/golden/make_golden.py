@@ -81,14 +81,25 @@ def write_csv_folder(arr, folder):
         w.writerow([arr.R, arr.M, arr.S, arr.ddt])
     with open(os.path.join(folder, "process_data.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kind", "task", "machine_selectable", "process_time"])
+        dyn = hasattr(arr, "power")
+        w.writerow(["kind", "task", "machine_selectable", "process_time"] + (["power"] if dyn else []))
         koff = arr.koff
         for r in range(arr.R):
             for j in range(int(arr.Jr[r])):
                 k = int(koff[r]) + j
                 ms = tuple(int(m) for m in arr.elig_list[k, :arr.elig_n[k]])
                 ts = tuple(int(arr.p[k, m]) for m in ms)
-                w.writerow([r, j, ms, ts])
+                w.writerow([r, j, ms, ts] + ([tuple(int(arr.power[k, m]) for m in ms)] if dyn else []))
+    if dyn:      # MO_DFJSP_instance_read.py:56-73: one row per breakdown window, or one bare row per machine
+        with open(os.path.join(folder, "machine_data.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            off = np.concatenate(([0], np.cumsum(arr.bk_n)))
+            w.writerow(["machine", "idle_power", "breakdown_start", "breakdown_end"] if off[-1] else ["machine", "idle_power"])
+            for m in range(arr.M):
+                if arr.bk_n[m] == 0:
+                    w.writerow([m, int(arr.idle_power[m])])
+                for q in range(int(off[m]), int(off[m + 1])):
+                    w.writerow([m, int(arr.idle_power[m]), int(arr.bk[q, 0]), int(arr.bk[q, 1])])
     with open(os.path.join(folder, "order_data.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["order", "time_arrive", "time_delivery", "kind_number"])
@@ -111,6 +122,13 @@ def check_loader_against_reference(arr, env):
         assert tuple(env.count_sr_dict[s]) == tuple(int(c) for c in arr.count[s])
         assert env.time_arrive_s_dict[s] == int(arr.arrive[s])
         assert env.time_delivery_s_dict[s] == int(arr.delivery[s])
+    if hasattr(env, "power_m_dict"):
+        off = np.concatenate(([0], np.cumsum(arr.bk_n)))
+        for m in range(arr.M):
+            assert env.power_m_dict[m] == int(arr.idle_power[m])
+            assert [tuple(w) for w in env.breakdown_m_dict[m]] == [tuple(int(v) for v in arr.bk[q]) for q in range(off[m], off[m + 1])]
+            for (r, j), pw in env.power_mrj_dict[m].items():
+                assert pw == int(arr.power[int(koff[r]) + j, m])
 
 
 LP_STATS = {"solves": 0, "max_obj_gap": 0.0, "max_infeas": 0.0}
@@ -170,6 +188,8 @@ def action_stream(kind, seed, n, flat=None):
     if kind[0] == "fixed":
         return np.tile(np.array(kind[1], np.uint8), (n, 1))
     rs = np.random.RandomState(seed)
+    if flat == "dyn":                          # MO_DFJSP_breakdown.py:32 actions_size = [12, 10]
+        return np.stack([rs.randint(0, 12, n), rs.randint(0, 10, n)], 1).astype(np.uint8)
     if flat:                                   # flat action in column 0 (MO_FJSSP_discretes / SO_SFJSP)
         return np.stack([rs.randint(0, flat, n), np.zeros(n, np.int64)], 1).astype(np.uint8)
     return np.stack([rs.randint(0, 6, n), rs.randint(0, 5, n)], 1).astype(np.uint8)
@@ -212,6 +232,9 @@ def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, ch
                 s, r, d = env.step([int(a[0]), int(a[1])])
             elif mo == "sf":
                 s, r, d = env.step(int(a[0]))
+            elif mo[0] == "dyn":
+                s, r, d = env.step([int(a[0]), int(a[1])], reward_policy=mo[1], completion=mo[2], tardiness=mo[3],
+                                   energy_consumption=mo[4])
             else:
                 s, r, d = env.step(int(a[0]), weight_vector=(mo[0], mo[1]), completion=mo[2], tardiness=mo[3])
             el += time.perf_counter() - t0
@@ -230,8 +253,9 @@ def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, ch
     out["tend"] = np.array([env.machine_dict[m].time_end for m in env.machine_tuple], np.int32)
     out["makespan"] = int(out["tend"].max())
     out["delay_time_sum"] = int(env.delay_time_sum)
-    out["fluid_completed_time"] = float(env.fluid_completed_time)
+    out["fluid_completed_time"] = float(getattr(env, "fluid_completed_time", -1.0))   # class_MODFJSP keeps none
     out["completion_time"] = int(getattr(env, "completion_time", 0))
+    out["energy"] = int(getattr(env, "energy_consumption", 0))
     out["T"] = t
     return out, env
 
@@ -242,6 +266,8 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
         env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_FJSSP, rng_seed)
     elif mo == "sf":
         env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_SFJSP, rng_seed)
+    elif mo[0] == "dyn":
+        env = pyoracle.OracleEnv(arr, lp, pyoracle.MO_DFJSP, rng_seed, ddt=arr.ddt)
     else:
         env = pyoracle.OracleEnv(arr, lp, pyoracle.MO_FJSSP_DISCRETES, rng_seed, ddt=arr.ddt)
     rec = {"k": [], "m": [], "job_r": [], "job_n": [], "reward": [], "done": [], "step_time": [], "delay": [],
@@ -253,6 +279,8 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
             s, r, d = env.step(actions[t])
         elif mo == "sf":
             s, r, d = env.step_sf(int(actions[t][0]))
+        elif mo[0] == "dyn":
+            s, r, d = env.step_dyn(actions[t], mo[1], mo[2], mo[3], mo[4])
         else:
             s, r, d = env.step_mo(int(actions[t][0]), (mo[0], mo[1]), mo[2], mo[3])
         tr = env.trace
@@ -268,6 +296,7 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
     out["delay_time_sum"] = env.delay_time_sum
     out["fluid_completed_time"] = env.fluid_completed_time
     out["completion_time"] = env.completion_time
+    out["energy"] = env.energy_consumption if mo is not None and mo != "sf" and mo[0] == "dyn" else 0
     out["T"] = t
     return out
 
@@ -291,9 +320,11 @@ def compare(ref, ora, tag):
             raise AssertionError("%s: state[%d][%d] ref %r oracle %r" % (tag, i, j, ref["states"][i][j], ora["states"][i][j]))
     assert np.array_equal(ref["tend"], ora["tend"]), tag + ": machine time_end"
     assert ref["makespan"] == ora["makespan"] and ref["delay_time_sum"] == ora["delay_time_sum"], tag
-    assert ref["fluid_completed_time"] == ora["fluid_completed_time"], tag + ": fluid_completed_time"
+    if ref["fluid_completed_time"] >= 0:
+        assert ref["fluid_completed_time"] == ora["fluid_completed_time"], tag + ": fluid_completed_time"
     if ref.get("completion_time"):
         assert ref["completion_time"] == ora["completion_time"], tag + ": completion_time"
+    assert ref.get("energy", 0) == ora.get("energy", 0), tag + ": energy_consumption"
 
 
 def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_states, mo=None):
@@ -311,7 +342,10 @@ def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_st
     store[prefix + "states_sha256"] = np.frombuffer(hashlib.sha256(bits(ref["states"]).tobytes()).digest(), np.uint8)
     store[prefix + "state_last"] = ref["states"][-1]
     store[prefix + "completion"] = np.int64(ref.get("completion_time", 0))
-    if mo is not None and mo != "sf":
+    store[prefix + "energy"] = np.int64(ref.get("energy", 0))
+    if mo is not None and mo != "sf" and mo[0] == "dyn":   # [reward_policy, completion, tardiness, energy] (-1 = None)
+        store[prefix + "mo"] = np.array([mo[1]] + [-1.0 if v is None else v for v in mo[2:5]], np.float64)
+    elif mo is not None and mo != "sf":
         store[prefix + "mo"] = np.array([mo[0], mo[1], -1.0 if mo[2] is None else mo[2], -1.0 if mo[3] is None else mo[3]], np.float64)
     if full_states:
         store[prefix + "states"] = ref["states"]
@@ -322,6 +356,9 @@ def store_instance(store, prefix, arr, name):
     for key in ("Jr", "p", "elig_n", "elig_list", "count", "arrive", "delivery", "x"):
         store[prefix + key] = getattr(arr, key)
     store[prefix + "ddt"] = np.float64(arr.ddt)
+    if hasattr(arr, "power"):
+        for key in ("power", "idle_power", "bk_n", "bk"):
+            store[prefix + key] = getattr(arr, key)
 
 
 def main():
@@ -332,6 +369,7 @@ def main():
     from environments.SO_FJSSP import SO_FJSSP_Environment
     from environments.MO_FJSSP_discretes import MO_FJSSP_Environment
     from environments.SO_SFJSP import SO_SFJSP_Environment
+    from environments.MO_DFJSP_breakdown import MO_DFJSP_Environment
 
     tmp = tempfile.mkdtemp(prefix="fjsp_golden_")
     report = []
@@ -341,7 +379,8 @@ def main():
         """cases: list of (label, arrays, folder_parent, folder_name)."""
         if args.only and args.only != name:
             return
-        EnvCls = {"so": SO_FJSSP_Environment, "mo": MO_FJSSP_Environment, "sf": SO_SFJSP_Environment}[variant]
+        EnvCls = {"so": SO_FJSSP_Environment, "mo": MO_FJSSP_Environment, "sf": SO_SFJSP_Environment,
+                  "dyn": MO_DFJSP_Environment}[variant]
         store = {}
         suite_base = splitmix64(sum(ord(ch) for ch in name) * 7919)
         store["rng_seed_base"] = np.uint64(suite_base)
@@ -356,13 +395,18 @@ def main():
             for plan in plans_store(ci) + [tuple(pl) + (False,) for pl in plans_verify(ci)]:
                 if variant in ("so", "sf"):
                     (kind, seed, keep), mo = plan, (None if variant == "so" else "sf")
+                elif variant == "dyn":
+                    # (kind, seed, reward_policy, keep); policy 3 takes its normalisers from the policy 0/1/2 runs
+                    kind, seed, policy, keep = plan
+                    mo = ("dyn", policy) + tuple(mo_memo.get(kk) if policy == 3 else None
+                                                 for kk in ("completion", "tardiness", "energy"))
                 else:
                     # (kind, seed, mo_spec, keep); mo_spec = (w0, w1, use_normalisers)
                     kind, seed, mo_spec, keep = plan
                     cn = mo_memo.get("completion") if mo_spec[2] else None
                     tn = mo_memo.get("tardiness") if mo_spec[2] else None
                     mo = (mo_spec[0], mo_spec[1], cn, tn)
-                actions = action_stream(kind, seed, Tmax, {"so": None, "mo": 18, "sf": 20}[variant])
+                actions = action_stream(kind, seed, Tmax, {"so": None, "mo": 18, "sf": 20, "dyn": "dyn"}[variant])
                 # stored episode e of a suite plays with random.choice stream seed
                 # suite_base + e * 1000003 == the seed env e of a batch created with
                 # rng_seed = suite_base gets (fjsp_kernels.hip bind()); verify-only
@@ -370,6 +414,9 @@ def main():
                 rng_seed = (suite_base + ep_id * 1000003) & MASK64 if keep else splitmix64(seed * 1000003 + ci)
                 ref, env = run_reference(EnvCls, arr, parent, folder, actions, rng_seed,
                                          check_lp=(n_eps % 16 == 0), timing=timing, mo=mo)
+                if variant == "dyn" and mo[1] != 3:
+                    mo_memo[("completion", "tardiness", "energy")[mo[1]]] = (ref["completion_time"], ref["delay_time_sum"],
+                                                                              ref["energy"])[mo[1]]
                 if variant == "mo" and mo != "sf":      # MPPPO.py:161-164: the single-objective runs supply the normalisers
                     if mo[0] == 1 and mo[2] is None:
                         mo_memo["completion"] = ref["completion_time"]
@@ -524,6 +571,49 @@ def main():
                       (("fixed", (13, 0)), 0, True)],
           lambda ci: [] if args.quick else [(("fixed", (a, 0)), 0) for a in range(20)],
           full_state_eps={0}, variant="sf")
+
+    # ---- suite 7: MO_DFJSP_breakdown (BASELINE config 5): order arrivals + machine breakdowns + energy ------
+    dyn_cases = [("industrial", "DDT0.5_M20_S1"), ("industrial", "DDT0.5_M20_S3"), ("industrial", "DDT0.5_M20_S5"),
+                 ("HMPSAC", "DDT0.5_M10_S1"), ("HMPSAC", "DDT1.0_M15_S3")]
+    if args.quick:
+        dyn_cases = dyn_cases[:2]
+    n_gen = 4
+    s7 = fi.InstanceSet(len(dyn_cases) + n_gen)
+    for i, (d, f) in enumerate(dyn_cases):
+        s7.load_csv(i, REF + "/data/" + d, f)
+    gen_prm = [dict(R_min=3, R_max=3, J_min=2, J_max=3, M=4, p_min=5, p_max=30, N_min=2, N_max=3, S=2, DDT=1.0),
+               dict(R_min=4, R_max=4, J_min=3, J_max=4, M=6, p_min=10, p_max=60, N_min=1, N_max=3, S=3, DDT=0.5),
+               dict(R_min=2, R_max=2, J_min=2, J_max=2, M=3, p_min=1, p_max=6, N_min=2, N_max=2, S=1, DDT=1.0),
+               dict(R_min=5, R_max=5, J_min=3, J_max=5, M=10, p_min=20, p_max=200, N_min=2, N_max=4, S=2, DDT=1.5)]
+    s7g = fi.InstanceSet(n_gen)
+    rs = np.random.RandomState(2024)
+    for i, kw in enumerate(gen_prm):
+        s7g.generate(i, 8800 + i, fi.GenParams(t_si_min=100.0, t_si_max=200.0, **kw))
+        a = s7g.arrays(i)
+        power = np.where(a.p > 0, rs.randint(1, 50, a.p.shape), 0)
+        idle = rs.randint(1, 10, a.M)
+        horizon = int(a.p.max()) * int(a.count.sum()) * int(a.Jr.max()) // a.M + 50
+        bk_n = rs.randint(0, 5, a.M)
+        bk = []
+        for m in range(a.M):                            # sorted disjoint windows; dense enough that every branch
+            t = 0                                       # of MO_DFJSP_breakdown.py:204-231 is taken
+            for _ in range(int(bk_n[m])):
+                st = t + int(rs.randint(1, max(2, horizon // 6)))
+                en = st + int(rs.randint(1, max(2, int(a.p.max()))))
+                bk.append((st, en)); t = en
+        s7g.set_dynamic(i, power, idle, bk_n, np.array(bk, np.int32).reshape(-1, 2))
+        write_csv_folder(s7g.arrays(i), os.path.join(tmp, "dyn", "D%d" % i))
+        s7.load_csv(len(dyn_cases) + i, os.path.join(tmp, "dyn"), "D%d" % i)
+    s7.solve_fluid()
+    cases = [(d + "/" + f, s7.arrays(i), REF + "/data/" + d, f) for i, (d, f) in enumerate(dyn_cases)]
+    cases += [("gen%d" % (8800 + i), s7.arrays(len(dyn_cases) + i), os.path.join(tmp, "dyn"), "D%d" % i) for i in range(n_gen)]
+    DYN_PAIRS = [("fixed", (a0, a1)) for a0 in range(12) for a1 in range(10)]
+    suite("mo_dfjsp", cases,
+          lambda ci: [(("random",), 601 + ci, 0, True), (("random",), 611 + ci, 1, True), (("random",), 621 + ci, 2, True),
+                      (("random",), 631 + ci, 3, True), (DYN_PAIRS[(ci * 37) % 120], 0, 3, True),
+                      (DYN_PAIRS[(ci * 53 + 67) % 120], 0, 2, True)],
+          lambda ci: ([] if args.quick else [(kp, 0, 3) for kp in (DYN_PAIRS if ci >= len(dyn_cases) else DYN_PAIRS[ci::7])]),
+          full_state_eps={0, 3}, variant="dyn")
 
     report.append("LP checks vs HiGHS on the reference-built model: %d solves, max objective gap %.2e, max infeasibility %.2e"
                   % (LP_STATS["solves"], LP_STATS["max_obj_gap"], LP_STATS["max_infeas"]))

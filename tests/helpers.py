@@ -8,6 +8,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SUITES = ("mk01", "synth10x5", "multijob", "large", "edge", "multiorder")      # SO_FJSSP (multiorder: S > 1)
 MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
 SF_SUITES = ("so_sfjsp",)                                    # SO_SFJSP
+DYN_SUITES = ("mo_dfjsp",)                                   # MO_DFJSP_breakdown (order arrivals, breakdowns, energy)
 ORACLE_ONLY_SUITES = ()
 
 # observation entries that pass through math.pow(x, 2) + sqrt in the reference
@@ -23,6 +24,9 @@ MO_EXACT_COLS = tuple(i for i in range(25) if i not in MO_POW_COLS)
 # SO_SFJSP state = [9 obs | 9 deltas]; pow()-derived: ct_std, cro_std, gap_std, gap_m_std (SO_SFJSP.py:68-81)
 SF_POW_COLS = (1, 3, 6, 8, 10, 12, 15, 17)
 SF_EXACT_COLS = tuple(i for i in range(18) if i not in SF_POW_COLS)
+# MO_DFJSP_breakdown state = [15 obs | 15 deltas]; pow()-derived: ct_std, cro_std, gap_std, gap_m_std (:103-116)
+DYN_POW_COLS = (3, 6, 8, 10, 18, 21, 23, 25)
+DYN_EXACT_COLS = tuple(i for i in range(30) if i not in DYN_POW_COLS)
 POW_RTOL = 1e-12   # north_star allows 1e-5; observed differences are <= a few ulp
 POW_ATOL = 1e-12   # the v(t) - v(t-1) half cancels, so an absolute floor is needed
 
@@ -38,6 +42,9 @@ def load_suite(name):
         a = Arrays()
         for key in ("Jr", "p", "elig_n", "elig_list", "count", "arrive", "delivery", "x"):
             setattr(a, key, z["i%d_%s" % (i, key)])
+        for key in ("power", "idle_power", "bk_n", "bk"):
+            if "i%d_%s" % (i, key) in z.files:
+                setattr(a, key, z["i%d_%s" % (i, key)])
         a.ddt = float(z["i%d_ddt" % i])
         a.name = str(z["i%d_name" % i])
         a.R, a.S = len(a.Jr), len(a.arrive)
@@ -50,7 +57,7 @@ def load_suite(name):
               "state0", "tend", "final", "states_sha256", "state_last")}
         if "e%d_states" % e in z.files:
             d["states"] = z["e%d_states" % e]
-        for opt in ("mo", "completion"):
+        for opt in ("mo", "completion", "energy"):
             if "e%d_%s" % (e, opt) in z.files:
                 d[opt] = z["e%d_%s" % (e, opt)]
         d["inst"] = int(d["inst"]); d["rng_seed"] = int(d["rng_seed"]); d["T"] = int(d["final"][2])
@@ -73,6 +80,8 @@ def instance_set_from(arrs):
     for i, a in enumerate(arrs):
         s.set_raw(i, a.Jr, a.p, a.elig_n, a.elig_list, a.count, a.arrive, a.delivery, a.ddt)
         s.set_x(i, a.x)
+        if hasattr(a, "power"):
+            s.set_dynamic(i, a.power, a.idle_power, a.bk_n, a.bk)
     return s
 
 
@@ -83,13 +92,15 @@ def play_oracle(arr, x, actions, rng_seed, variant=0, mo=None):
     if arr.S > 1:        # order arrivals re-solve the LP on the live state (class_FJSSP.py:239): product LP as the hook
         from deep_reinforcement_learning_for_fjsp_amd import instances as fi
         x = lambda Q, now: fi.fluid_lp(arr.Jr, arr.p, Q, now)[0]
-    env = pyoracle.OracleEnv(arr, x, variant, rng_seed, ddt=getattr(arr, "ddt", None) if variant == 2 else None)
+    env = pyoracle.OracleEnv(arr, x, variant, rng_seed, ddt=getattr(arr, "ddt", None) if variant in (2, 4) else None)
     rec = {k: [] for k in ("k", "m", "job_r", "job_n", "reward", "done", "step_time", "delay", "states")}
     state0 = env.reset()
     t = 0
     while not env.done:
         if mo is None and variant == 1:
             s, r, d = env.step_sf(int(actions[t][0]))
+        elif variant == 4:   # mo = (reward_policy, completion, tardiness, energy), <= 0 standing for None
+            s, r, d = env.step_dyn(actions[t], int(mo[0]), *[v if v > 0 else None for v in mo[1:4]])
         elif mo is None:
             s, r, d = env.step(actions[t])
         else:
@@ -103,16 +114,18 @@ def play_oracle(arr, x, actions, rng_seed, variant=0, mo=None):
     out = {k: np.array(v) for k, v in rec.items()}
     out.update(state0=state0, tend=env.machine_time_end(), makespan=env.makespan, delay_time_sum=env.delay_time_sum,
                T=t, fluid_completed_time=env.fluid_completed_time, completion_time=env.completion_time)
+    if variant == 4:
+        out["energy"] = env.energy_consumption
     return out
 
 
-def assert_state_close(got, want, what="", mo=False, sf=False):
+def assert_state_close(got, want, what="", mo=False, sf=False, dyn=False):
     """Kernel state vs oracle/reference state: bit-exact except the pow()-derived entries."""
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
-    ex = list(SF_EXACT_COLS if sf else (MO_EXACT_COLS if mo else EXACT_COLS))
+    ex = list(DYN_EXACT_COLS if dyn else (SF_EXACT_COLS if sf else (MO_EXACT_COLS if mo else EXACT_COLS)))
     if not np.array_equal(bits(got[..., ex]), bits(want[..., ex])):
         bad = np.argwhere(bits(got[..., ex]) != bits(want[..., ex]))[0]
         raise AssertionError("%s exact state entry differs at %s: got %r want %r"
                              % (what, bad, got[..., ex][tuple(bad)], want[..., ex][tuple(bad)]))
-    pw = list(SF_POW_COLS if sf else (MO_POW_COLS if mo else POW_COLS))
+    pw = list(DYN_POW_COLS if dyn else (SF_POW_COLS if sf else (MO_POW_COLS if mo else POW_COLS)))
     np.testing.assert_allclose(got[..., pw], want[..., pw], rtol=POW_RTOL, atol=POW_ATOL, err_msg=what)

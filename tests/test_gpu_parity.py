@@ -213,6 +213,118 @@ def test_so_sfjsp_matches_reference_fixtures(torch_gpu):
             assert fin["status"][e] & ~4 == 0, tag
 
 
+def test_mo_dfjsp_breakdown_matches_reference_fixtures(torch_gpu):
+    """MO_DFJSP_breakdown (BASELINE config 5): order arrivals + machine breakdowns + energy, 12 x 10 rules,
+    reward policies 0..3, against the reference traces (MO_DFJSP_breakdown.py:189-447)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, VARIANT_MO_DFJSP
+    insts, eps, base = H.load_suite("mo_dfjsp")
+    s = H.instance_set_from([insts[ep["inst"]] for ep in eps])
+    T = max(ep["T"] for ep in eps)
+    actions = np.zeros((T, len(eps), 2), np.uint8)
+    for e, ep in enumerate(eps):
+        actions[:ep["T"], e] = ep["actions"]
+    actions = torch.from_numpy(actions).cuda()
+    mo = torch.from_numpy(np.stack([np.maximum(ep["mo"], 0.0) for ep in eps])).cuda()      # -1 = None -> unused
+    for mode in ("step", "rollout"):
+        b = EnvBatch(s, len(eps), variant=VARIANT_MO_DFJSP, rng_seed=base)
+        assert b.state_size == 30
+        st0 = b.reset().cpu().numpy()
+        for e, ep in enumerate(eps):
+            H.assert_state_close(st0[e], ep["state0"], "dyn ep %d reset" % e, dyn=True)
+        if mode == "step":
+            rewards = np.zeros((T, len(eps))); states = np.zeros((T, len(eps), 30))
+            done_at = np.full(len(eps), -1)
+            for t in range(T):
+                alive = (b.done == 0).cpu().numpy()
+                st, r, d = b.step(actions[t], mo=mo)
+                rewards[t] = r.cpu().numpy(); states[t] = st.cpu().numpy()
+                d = d.cpu().numpy()
+                done_at[(done_at < 0) & alive & (d == 1)] = t
+            trace = None
+            for e, ep in enumerate(eps):
+                assert done_at[e] == ep["T"] - 1, "dyn episode %d finished at step %d, reference %d" % (e, done_at[e], ep["T"] - 1)
+        else:
+            trace, rw, st = b.rollout(actions, mo=mo)
+            trace = trace.cpu().numpy(); rewards = rw.cpu().numpy(); last = st.cpu().numpy()
+        fin = {k: v.cpu().numpy() for k, v in b.read().items()}
+        tend = b.machine_time_end().cpu().numpy()
+        for e, ep in enumerate(eps):
+            Te = ep["T"]
+            tag = "mo_dfjsp %s episode %d (%s)" % (mode, e, insts[ep["inst"]].name)
+            assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(ep["reward"])), tag + " reward"
+            if trace is not None:
+                assert np.array_equal(trace[:Te, e, 0], ep["k"]) and np.array_equal(trace[:Te, e, 1], ep["m"]), tag
+                H.assert_state_close(last[e], ep["state_last"], tag, dyn=True)
+            else:
+                H.assert_state_close(states[Te - 1, e], ep["state_last"], tag, dyn=True)
+                if "states" in ep:
+                    H.assert_state_close(states[:Te, e], ep["states"], tag, dyn=True)
+            M = insts[ep["inst"]].M
+            assert np.array_equal(tend[e, :M], ep["tend"]), tag
+            assert fin["makespan"][e] == ep["final"][0] and fin["delay_time_sum"][e] == ep["final"][1], tag
+            assert fin["completion_time"][e] == int(ep["completion"]) and fin["step_count"][e] == Te, tag
+            assert fin["energy_consumption"][e] == int(ep["energy"]), tag + " energy"
+            assert fin["status"][e] & ~4 == 0, tag
+
+
+def test_mo_dfjsp_single_env_mirror(torch_gpu, tmp_path):
+    """environments.MO_DFJSP_breakdown.MO_DFJSP_Environment: the reference's constructor / step signature over
+    a CSV folder (written from a fixture instance), including the 1-element flat action (:191-192)."""
+    import csv
+    from deep_reinforcement_learning_for_fjsp_amd.environments import MO_DFJSP_Environment
+    from deep_reinforcement_learning_for_fjsp_amd.utilities.Utility_Class import MyError
+    insts, eps, base = H.load_suite("mo_dfjsp")
+    ep = next(e for e in eps if insts[e["inst"]].name.startswith("gen") and e["mo"][0] == 1)
+    a = insts[ep["inst"]]
+    folder = tmp_path / "D0"
+    folder.mkdir()
+    koff = np.concatenate(([0], np.cumsum(a.Jr)))
+    with open(folder / "based_data.csv", "w", newline="") as f:
+        csv.writer(f).writerows([["kind_count", "machine_count", "order_count", "DDT"], [a.R, a.M, a.S, a.ddt]])
+    with open(folder / "process_data.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kind", "task", "machine_selectable", "process_time", "power"])
+        for r in range(a.R):
+            for j in range(int(a.Jr[r])):
+                k = int(koff[r]) + j
+                ms = tuple(int(m) for m in a.elig_list[k, :a.elig_n[k]])
+                w.writerow([r, j, ms, tuple(int(a.p[k, m]) for m in ms), tuple(int(a.power[k, m]) for m in ms)])
+    with open(folder / "order_data.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["order", "time_arrive", "time_delivery", "kind_number"])
+        for so in range(a.S):
+            w.writerow([so, int(a.arrive[so]), int(a.delivery[so]), tuple(int(c) for c in a.count[so])])
+    with open(folder / "machine_data.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["machine", "idle_power", "breakdown_start", "breakdown_end"])
+        off = np.concatenate(([0], np.cumsum(a.bk_n)))
+        for m in range(a.M):
+            if a.bk_n[m] == 0:
+                w.writerow([m, int(a.idle_power[m])])
+            for q in range(int(off[m]), int(off[m + 1])):
+                w.writerow([m, int(a.idle_power[m]), int(a.bk[q, 0]), int(a.bk[q, 1])])
+    env = MO_DFJSP_Environment(use_instance=False, path=str(tmp_path), file_name="D0", rng_seed=ep["rng_seed"])
+    assert env.state_size == 30 and env.actions_size == [12, 10]
+    st = env.reset()
+    H.assert_state_close(st, ep["state0"], "mirror reset", dyn=True)
+    t = 0
+    while not env.done:
+        a0, a1 = int(ep["actions"][t][0]), int(ep["actions"][t][1])
+        act = [a0, a1] if t % 2 else [a0 * 10 + a1]          # both action forms
+        st, r, d = env.step(act, reward_policy=1)
+        assert r == ep["reward"][t] and env.step_time == ep["step_time"][t] and env.delay_time_sum == ep["delay"][t]
+        t += 1
+    assert t == ep["T"] and env.energy_consumption == int(ep["energy"]) and env.completion_time == int(ep["completion"])
+    H.assert_state_close(st, ep["state_last"], "mirror last", dyn=True)
+    assert max(mv.time_end for mv in env.machine_dict.values()) == ep["final"][0]
+    env.reset()
+    with pytest.raises(MyError):
+        env.step([0, 0], reward_policy=7)
+    with pytest.raises(MyError):
+        env.step([12, 0], reward_policy=0)
+
+
 def test_full_size_batch_against_oracle_and_invariants(torch_gpu):
     """BASELINE config 2 at full size: 4096 generated 10x5 instances (seeds 1000+i), random policy.
 

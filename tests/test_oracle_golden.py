@@ -10,7 +10,7 @@ import pytest
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES + H.SF_SUITES + H.ORACLE_ONLY_SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES + H.SF_SUITES + H.DYN_SUITES + H.ORACLE_ONLY_SUITES)
 def test_oracle_matches_reference_fixtures(built, suite):
     insts, eps, _ = H.load_suite(suite)
     assert eps, "empty fixture"
@@ -19,6 +19,9 @@ def test_oracle_matches_reference_fixtures(built, suite):
         if suite in H.MO_SUITES:
             got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=2, mo=ep["mo"])
             assert got["completion_time"] == int(ep["completion"])
+        elif suite in H.DYN_SUITES:
+            got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=4, mo=ep["mo"])
+            assert got["completion_time"] == int(ep["completion"]) and got["energy"] == int(ep["energy"])
         elif suite in H.SF_SUITES:
             got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=1)
             assert got["completion_time"] == int(ep["completion"]) == int(ep["final"][0])
