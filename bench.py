@@ -192,13 +192,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d parallel SO_FJSSP 10x5 generated instances per GPU "
-                                   "(seeds 1000+i), random policy, per-step HIP kernel (step_kernel<1>) with autoreset, "
+                                   "(seeds 1000+i), random policy, per-step HIP kernel (step_kernel<KC=1, V=SO_FJSSP>) with autoreset, "
                                    "one launch = one env step of every env" % N,
                        "envs_per_gpu": N, "mean_ops_per_instance": float(K.mean()), "sharding": "env id range per rank, no collective",
                        "host_prep_s": round(t_prep, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "step_kernel<1>", "bytes_per_env_step": env.step_bytes,
+                         "kernel": "step_kernel<1, 0>", "bytes_per_env_step": env.step_bytes,
                          "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": region_us,
                          "launch_us_per_launch_events": kern_us},
             "cpu_baseline": cpu,

@@ -122,6 +122,14 @@ class EnvBatch(object):
             check(self._lib.fjsp_env_energy(self._h, _ptr(out["energy_consumption"]), self._stream()))
         return out
 
+    def set_lp_threads(self, n_threads):
+        """Host threads of the order-arrival LP service (0 = all cores)."""
+        check(self._lib.fjsp_env_set_lp_threads(self._h, int(n_threads)))
+
+    @property
+    def lp_solves(self):
+        return int(self._lib.fjsp_env_lp_solves(self._h))
+
     def machine_time_end(self):
         d = self.instances.dims(self.first)
         mp = max(self.instances.dims(self.first + i)["M"] for i in range(self.n_inst)) if self.n_inst > 1 else d["M"]

@@ -3,9 +3,12 @@
 // of environments and launches the kernels of fjsp_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fjsp_amd.h"
@@ -27,6 +30,10 @@ struct fjsp_env {
     const fjsp_instances *src = nullptr;
     int first = 0;
     std::vector<uint32_t> h_pending;
+    std::vector<uint16_t> h_lpq;
+    std::vector<double> h_xin;
+    int lp_threads = 0;         // 0 = all host cores
+    int64_t lp_solves = 0;      // order-arrival LPs solved so far
 };
 
 namespace {
@@ -340,12 +347,19 @@ int fjsp_env_num_envs(const fjsp_env *e) { return e ? e->b.N : 0; }
 int fjsp_env_state_size(const fjsp_env *e) { return e ? e->b.state_size : 0; }
 int fjsp_env_device(const fjsp_env *e) { return e ? e->device : -1; }
 int64_t fjsp_env_step_bytes(const fjsp_env *e) { return e ? e->step_bytes : 0; }
+int64_t fjsp_env_lp_solves(const fjsp_env *e) { return e ? e->lp_solves : 0; }
+int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads) {
+    if (!e || n_threads < 0) { set_error("fjsp_env_set_lp_threads: bad arguments"); return FJSP_E_ARG; }
+    e->lp_threads = n_threads;
+    return FJSP_OK;
+}
 
 namespace {
 // Multi-order batches: after a step launch, solve the fluid LP of every env that stopped at an order
 // arrival (class_FJSSP.py:239 on the live state) with the host simplex and let arrival_kernel finish
 // those steps.  Synchronises the stream: order arrivals make step() blocking for such batches.
-int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace, hipStream_t st) {
+int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace,
+                     hipStream_t st) {
     const DevBatch &b = e->b;
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, b.pending_count, 4, hipMemcpyDeviceToHost, st));
@@ -354,26 +368,60 @@ int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d
     e->h_pending.resize(n);
     HIP_TRY(hipMemcpy(e->h_pending.data(), b.pending_count + 1, (size_t)n * 4, hipMemcpyDeviceToHost));
     const size_t KP = (size_t)b.KP, MP = (size_t)b.MP;
-    std::vector<uint16_t> lpq(2 * KP);
-    std::vector<double> xin(KP * MP), xk;
-    std::vector<int> Q, now;
-    for (uint32_t q = 0; q < n; ++q) {
-        const int env = (int)e->h_pending[q];
-        const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
-        unsigned char *rec = b.envs + (size_t)env * b.L.e_stride;
-        HIP_TRY(hipMemcpy(lpq.data(), rec + b.L.e_lpq, 2 * KP * 2, hipMemcpyDeviceToHost));
-        Q.assign(in.K, 0); now.assign(in.K, 0);
-        for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
-        xk.assign((size_t)in.K * in.M, 0.0);
-        double obj = 0.0;
-        if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) return FJSP_E_LP;
-        std::fill(xin.begin(), xin.end(), 0.0);
-        for (int k = 0; k < in.K; ++k)
-            for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
-        HIP_TRY(hipMemcpy(rec + b.L.e_xin, xin.data(), KP * MP * 8, hipMemcpyHostToDevice));
+    // LP inputs of every parked env in one strided copy each way (a parked env's record is not touched by
+    // anything else until arrival_kernel runs)
+    e->h_lpq.resize((size_t)n * 2 * KP);
+    e->h_xin.assign((size_t)n * KP * MP, 0.0);
+    for (uint32_t q = 0; q < n; ++q)
+        HIP_TRY(hipMemcpyAsync(e->h_lpq.data() + (size_t)q * 2 * KP, b.envs + (size_t)e->h_pending[q] * b.L.e_stride + b.L.e_lpq,
+                               2 * KP * 2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // one LP per parked env, independent: spread over the host cores
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> fail{0};
+    std::string err;
+    std::mutex err_mu;
+    auto work = [&]() {
+        std::vector<int> Q, now;
+        std::vector<double> xk;
+        for (;;) {
+            const uint32_t q = next.fetch_add(1);
+            if (q >= n || fail.load()) return;
+            const int env = (int)e->h_pending[q];
+            const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
+            const uint16_t *lpq = e->h_lpq.data() + (size_t)q * 2 * KP;
+            Q.assign(in.K, 0); now.assign(in.K, 0);
+            for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
+            xk.assign((size_t)in.K * in.M, 0.0);
+            double obj = 0.0;
+            if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (fail.fetch_add(1) == 0) err = fjsp_last_error();     // thread-local message of this worker
+                return;
+            }
+            double *xin = e->h_xin.data() + (size_t)q * KP * MP;
+            for (int k = 0; k < in.K; ++k)
+                for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
+        }
+    };
+    int n_threads = e->lp_threads > 0 ? e->lp_threads : (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    if ((uint32_t)n_threads > n) n_threads = (int)n;
+    if (n_threads == 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
+        for (auto &t : th) t.join();
     }
+    if (fail.load()) { set_error(err); return FJSP_E_LP; }
+    for (uint32_t q = 0; q < n; ++q)
+        HIP_TRY(hipMemcpyAsync(b.envs + (size_t)e->h_pending[q] * b.L.e_stride + b.L.e_xin, e->h_xin.data() + (size_t)q * KP * MP,
+                               KP * MP * 8, hipMemcpyHostToDevice, st));
     if (launch_arrival(b, d_mo, (int)n, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
     HIP_TRY(hipMemsetAsync(b.pending_count, 0, 4, st));
+    // the staging buffers are reused by the next service call: the uploads must have left the host
+    HIP_TRY(hipStreamSynchronize(st));
+    e->lp_solves += n;
     return FJSP_OK;
 }
 }  // namespace

@@ -194,6 +194,10 @@ int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
 int fjsp_pyset_and_order(uint32_t idle_mask, const int32_t *machines, int32_t n, int32_t ascending, int32_t *out);
 /* HBM bytes the step kernel reads+writes per env-step (algorithmic). */
 int64_t fjsp_env_step_bytes(const fjsp_env *e);
+/* Order arrivals (SO_FJSSP.py:218-231) re-solve the fluid LP on the host, one LP per arriving env, spread
+ * over n_threads host threads (0 = all cores; default).  fjsp_env_lp_solves: LPs solved so far. */
+int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads);
+int64_t fjsp_env_lp_solves(const fjsp_env *e);
 
 /* ------------------------------------------------------------------------- *
  * Rollout buffer (on-policy Replay_Buffer, agents/MPPPO/Buffer.py:7-58) in HBM
