@@ -12,7 +12,6 @@ step() blocking for this environment.  Nothing is computed in Python.
 """
 import random
 
-import numpy as np
 import torch
 
 from .. import instances as _inst
@@ -71,10 +70,7 @@ class MO_DFJSP_Environment(object):
             seed = random.getrandbits(63) if seed is None else seed
             self.file_name = "DDT" + str(kwargs["DDT"]) + "_M" + str(kwargs["M"]) + "_S" + str(kwargs["S"])
             self._set.generate(0, seed, _inst.reference_generator_params(kwargs["DDT"], kwargs["M"], kwargs["S"]))
-            a = self._set.arrays(0)
-            rs = np.random.RandomState(seed & 0x7FFFFFFF)
-            power = np.where(a.p > 0, rs.randint(10, 201, a.p.shape), 0)        # p_rjm, Instance_generate.py:61-62
-            self._set.set_dynamic(0, power, rs.randint(1, 10, a.M), np.zeros(a.M, np.int32), np.zeros((0, 2), np.int32))
+            self._set.generate_machine_data(0, seed)                            # p_rjm / p_m_idle, Instance_generate.py:61-66
         else:
             self.path, self.file_name = kwargs["path"], kwargs["file_name"]
             self._set.load_csv(0, self.path, self.file_name)

@@ -152,6 +152,26 @@ class InstanceSet(object):
                                                    ptr(bk) if len(bk) else None))
         return self
 
+    def generate_machine_data(self, i, seed, max_windows=0, window_gap=(50, 400), window_len=(5, 60)):
+        """Machine data for a generated instance, drawn like the reference's generator: processing power
+        U{10..200} per eligible pair, idle power U{1..9} per machine (Instance_generate.py:61-66,90-91).  The
+        generator has no breakdowns (that data only exists in CSV folders, MO_DFJSP_instance_read.py:56-73);
+        max_windows > 0 adds up to that many sorted, disjoint windows per machine for synthetic batches."""
+        a = self.arrays(i)
+        rs = np.random.RandomState(int(seed) & 0x7FFFFFFF)
+        power = np.where(a.p > 0, rs.randint(10, 201, a.p.shape), 0)
+        idle = rs.randint(1, 10, a.M)
+        bk_n = rs.randint(0, max_windows + 1, a.M) if max_windows > 0 else np.zeros(a.M, np.int64)
+        bk = []
+        for m in range(a.M):
+            t = 0
+            for _ in range(int(bk_n[m])):
+                st = t + int(rs.randint(window_gap[0], window_gap[1] + 1))
+                en = st + int(rs.randint(window_len[0], window_len[1] + 1))
+                bk.append((st, en))
+                t = en
+        return self.set_dynamic(i, power, idle, bk_n, np.array(bk, np.int32).reshape(-1, 2))
+
 
 def fluid_lp(Jr, p, Q, n_now):
     """One fluid LP for a live state (class_FJSSP.py:246-280). Returns (x[K,M], objective)."""

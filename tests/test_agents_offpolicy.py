@@ -1,0 +1,146 @@
+"""CPU: the off-policy / actor-critic update math of the DDQN and HMPSAC counterparts against per-sample
+restatements of the reference formulas (agents/DDQN/DDQN.py:182-209, agents/HMPSAC/SAC_Discrete.py:265-338,
+agents/HMPSAC/A3C_v5.1.py:373-418), and the replay memories."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from deep_reinforcement_learning_for_fjsp_amd.utilities.data_structures.Replay_Buffer import DeviceReplayBuffer, Replay_Buffer
+from deep_reinforcement_learning_for_fjsp_amd.utilities.data_structures.Config import Config
+
+
+def test_config_table_matches_the_reference_values():
+    hp = Config().hyper_parameters
+    assert hp["DDQN"]["batch_size"] == 1280 and hp["DDQN"]["learning_rate"] == 1e-6 and hp["DDQN"]["discount_rate"] == 1
+    assert hp["HMP_SAC"]["min_steps_before_learning"] == 10000 and hp["HMP_SAC"]["update_every_n_steps"] == 1000
+    assert hp["DA3C"]["exploration_worker_difference"] == 2.0 and hp["MP_PPO"]["clip_epsilon"] == 0.2
+
+
+def test_reference_replay_buffer_mirror():
+    buf = Replay_Buffer(5, 3, device="cpu")
+    for i in range(7):
+        buf.add_experience(np.full(4, i, np.float64), i, -float(i), np.full(4, i + 1, np.float64), i == 6)
+    assert len(buf) == 5                                   # deque(maxlen)
+    s, a, r, n, d = buf.sample()
+    assert s.shape == (3, 4) and a.shape == (3, 1) and s.dtype == torch.float32
+    assert torch.equal(n[:, 0], s[:, 0] + 1) and torch.equal(r[:, 0], -a[:, 0]) and float(s.min()) >= 2
+    assert len(set(a[:, 0].tolist())) == 3                 # random.sample: without replacement
+    buf.add_experience([np.zeros(4)] * 2, [1, 2], [0.0, 0.0], [np.zeros(4)] * 2, [False, True])   # list form :20-24
+    assert len(buf) == 5
+
+
+def test_device_replay_ring():
+    buf = DeviceReplayBuffer(8, 4, 3, "cpu", seed=1)
+    mk = lambda lo, n: (torch.arange(lo, lo + n).double().unsqueeze(1).repeat(1, 3), torch.arange(lo, lo + n),
+                        -torch.arange(lo, lo + n).double(), torch.arange(lo, lo + n).double().unsqueeze(1).repeat(1, 3) + 0.5,
+                        torch.zeros(n, dtype=torch.uint8))
+    assert buf.add_batch(*mk(0, 5), active=torch.tensor([1, 1, 0, 1, 1])) == 4 and len(buf) == 4
+    assert buf.add_batch(*mk(10, 6)) == 6 and len(buf) == 8            # wraps: oldest two rows overwritten
+    kept = sorted(buf.actions[:, 0].tolist())
+    assert kept == [3.0, 4.0, 10.0, 11.0, 12.0, 13.0, 14.0, 15.0]
+    s, a, r, n, d = buf.sample()
+    assert s.shape == (4, 3) and len(set(a[:, 0].tolist())) == 4
+    assert torch.equal(s[:, 0], a[:, 0]) and torch.equal(r[:, 0], -a[:, 0]) and torch.equal(n[:, 0], a[:, 0] + 0.5)
+    buf.add_experience(np.ones(3), 7, 1.5, np.zeros(3), True)
+    assert len(buf) == 8 and 7.0 in buf.actions[:, 0].tolist()
+    with pytest.raises(AssertionError):
+        DeviceReplayBuffer(8, 4, 3, "cpu").sample()
+
+
+def test_ddqn_loss_is_double_q_learning():
+    from deep_reinforcement_learning_for_fjsp_amd.agents.DDQN.DDQN import ActorNet, ExplorationStrategy, ddqn_loss
+    torch.manual_seed(0)
+    local, target = ActorNet(18, 16, 2, 20), ActorNet(18, 16, 2, 20)
+    local.eval(); target.eval()
+    B = 12
+    s, n = torch.randn(B, 18), torch.randn(B, 18)
+    a = torch.randint(0, 20, (B, 1)).float()
+    r = torch.randn(B, 1)
+    d = (torch.rand(B, 1) < 0.3).float()
+    loss = ddqn_loss(local, target, s, a, r, n, d, 0.9)
+    want = 0.0
+    with torch.no_grad():
+        ql, qt, qn = local(s), target(n), local(n)
+        for i in range(B):
+            best = int(torch.argmax(qn[i]))                                   # DDQN.py:195
+            y = float(r[i]) + 0.9 * float(qt[i, best]) * (1 - float(d[i]))   # :196,201
+            want += (float(ql[i, int(a[i])]) - y) ** 2
+    assert math.isclose(float(loss.detach()), want / B, rel_tol=1e-5)
+    ex = ExplorationStrategy(1.0, 0.01, 10)
+    q = torch.zeros(1000, 20); q[:, 7] = 1.0
+    acts = ex.get_action(q)
+    assert abs(ex.epsilon - (1.0 - 0.099)) < 1e-12 and 0.02 < float((acts == 7).float().mean()) < 0.3
+    assert bool((ex.get_action(q, turn_off_exploration=True) == 7).float().mean() > 0.97) and ex.epsilon == 0.01
+
+
+def test_sac_discrete_losses():
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.SAC_Discrete import (PolicyNet, produce_action_and_action_info,
+                                                                                    sac_actor_loss, sac_critic_losses)
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.A3C import CriticNet
+    torch.manual_seed(1)
+    actor = PolicyNet(30, 16, 2, 3)
+    c1, c2, t1, t2 = (CriticNet(30, 16, 2, 3) for _ in range(4))
+    B, alpha, gamma = 10, 0.37, 0.99
+    s, n = torch.randn(B, 30), torch.randn(B, 30)
+    a = torch.randint(0, 3, (B, 1)).float()
+    r = torch.randn(B, 1)
+    d = (torch.rand(B, 1) < 0.3).float()
+    l1, l2 = sac_critic_losses(actor, c1, c2, t1, t2, alpha, (s, a, r, n, d), gamma)
+    with torch.no_grad():
+        p = actor(n); lp = torch.log(p)
+        w1 = w2 = 0.0
+        for i in range(B):
+            v = sum(float(p[i, k]) * (min(float(t1(n)[i, k]), float(t2(n)[i, k])) - alpha * float(lp[i, k])) for k in range(3))
+            y = float(r[i]) + (1.0 - float(d[i])) * gamma * v                 # SAC_Discrete.py:316
+            w1 += (float(c1(s)[i, int(a[i])]) - y) ** 2
+            w2 += (float(c2(s)[i, int(a[i])]) - y) ** 2
+    assert math.isclose(float(l1), w1 / B, rel_tol=1e-4) and math.isclose(float(l2), w2 / B, rel_tol=1e-4)
+    pl, log_pi = sac_actor_loss(actor, c1, c2, alpha, s)
+    with torch.no_grad():
+        p = actor(s); lp = torch.log(p)
+        want = np.mean([sum(float(p[i, k]) * (alpha * float(lp[i, k]) - min(float(c1(s)[i, k]), float(c2(s)[i, k])))
+                            for k in range(3)) for i in range(B)])
+        ent = [sum(float(p[i, k]) * float(lp[i, k]) for k in range(3)) for i in range(B)]
+    assert math.isclose(float(pl), want, rel_tol=1e-4, abs_tol=1e-6)
+    np.testing.assert_allclose(log_pi.detach().numpy(), ent, rtol=1e-4, atol=1e-6)
+    # zero-probability guard (:272-274)
+    class Hard(torch.nn.Module):
+        def forward(self, x):
+            return torch.tensor([[1.0, 0.0, 0.0]]).repeat(x.shape[0], 1)
+    _, (pp, lpp), mx = produce_action_and_action_info(Hard(), s)
+    assert torch.isfinite(lpp).all() and float(lpp[0, 1]) == pytest.approx(math.log(1e-8)) and int(mx[0]) == 0
+
+
+def test_a2c_returns_and_losses_per_episode():
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.A3C import a2c_losses, episode_returns, zscore_returns
+    rs = np.random.RandomState(3)
+    T, N, gamma = 9, 5, 0.99
+    lens = [9, 4, 1, 7, 0]
+    valid = torch.tensor([[1.0 if t < lens[e] else 0.0 for e in range(N)] for t in range(T)], dtype=torch.float64)
+    rewards = torch.from_numpy(-rs.randint(0, 50, (T, N)).astype(np.float64))
+    G = episode_returns(rewards, valid, gamma)
+    Z = zscore_returns(G, valid)
+    lp_t, lp_m = torch.from_numpy(rs.randn(T, N)), torch.from_numpy(rs.randn(T, N))
+    values = torch.from_numpy(rs.randn(T, N))
+    c, lt, lm = a2c_losses(lp_t, lp_m, values, Z, valid)
+    wc, wt, wm, live = 0.0, 0.0, 0.0, 0
+    for e in range(N):
+        L = lens[e]
+        if L == 0:
+            assert float(G[:, e].abs().sum()) == 0.0
+            continue
+        rew = rewards[:L, e].tolist()
+        ret = [0.0]
+        for ix in range(L):                                                    # A3C_v5.1.py:377-382
+            ret.append(rew[-(ix + 1)] + gamma * ret[-1])
+        ret = np.array(ret[1:][::-1])
+        np.testing.assert_allclose(G[:L, e].numpy(), ret, rtol=1e-12)
+        z = (ret - ret.mean()) / (ret.std() + 1e-5)                            # :385-391
+        np.testing.assert_allclose(Z[:L, e].numpy(), z, rtol=1e-9, atol=1e-12)
+        adv = z - values[:L, e].numpy()
+        wc += np.mean(adv ** 2); wt += np.mean(-lp_t[:L, e].numpy() * adv); wm += np.mean(-lp_m[:L, e].numpy() * adv)
+        live += 1
+    assert math.isclose(float(c), wc / live, rel_tol=1e-9)
+    assert math.isclose(float(lt), wt / live, rel_tol=1e-9) and math.isclose(float(lm), wm / live, rel_tol=1e-9)

@@ -108,3 +108,96 @@ def test_multi_policy_ppo_on_mo_discretes(torch_gpu):
     assert any(not torch.equal(b, p) for b, p in zip(before, agent.learners[2].actor_new.parameters()))
     chosen = agent.multi_policy_update(hist[-1])
     assert set(chosen) == set(range(5)) and all(0 <= v < 5 for v in chosen.values())
+
+
+def _dyn_instances(n, seed0, S=2, M=6, max_windows=2):
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    s = fi.InstanceSet(n)
+    prm = fi.GenParams(R_min=3, R_max=4, J_min=2, J_max=3, M=M, p_min=5, p_max=40, N_min=1, N_max=3, S=S, DDT=1.0,
+                       t_si_min=100.0, t_si_max=200.0)
+    for i in range(n):
+        s.generate(i, seed0 + i, prm)
+        s.generate_machine_data(i, seed0 + i, max_windows=max_windows, window_gap=(10, 80), window_len=(3, 20))
+    return s.solve_fluid()
+
+
+def test_ddqn_rounds_on_so_sfjsp(torch_gpu):
+    """agents/DDQN/DDQN.py end to end on batches of the environment it instantiates (SO_SFJSP): replay ring
+    fills with one transition per operation, the double-Q update moves the local net, the target follows by tau."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedSOSFJSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.DDQN.DDQN import DDQN
+    N = 128
+    test_set = fi.InstanceSet(8).generate_range(7000, fi.bench_10x5_params()).solve_fluid()
+    test_env = BatchedSOSFJSP(test_set, rng_seed=5)
+    rounds = [0]
+
+    def make_train_env():
+        rounds[0] += 1
+        s = fi.InstanceSet(N).generate_range(20000 * rounds[0], fi.bench_10x5_params()).solve_fluid()
+        return BatchedSOSFJSP(s, rng_seed=rounds[0])
+
+    torch.manual_seed(0)
+    agent = DDQN(make_train_env, test_env, hidden_size=64, hidden_layer=2, seed=3, updates_per_round=4,
+                 hyper={"batch_size": 512, "buffer_size": 20000, "learning_rate": 1e-3, "num_episodes_to_run": 20})
+    before = [p.detach().clone() for p in agent.q_network_local.parameters()]
+    tgt_before = [p.detach().clone() for p in agent.q_network_target.parameters()]
+    tests = [agent.step() for _ in range(3)]
+    assert all(np.isfinite(t) and t > 0 for t in tests)
+    n_ops = agent.global_step_number
+    assert len(agent.memory) == min(n_ops, 20000) and n_ops > 3 * N * 25
+    assert agent.last_loss is not None and np.isfinite(agent.last_loss)
+    assert any(not torch.equal(b, p) for b, p in zip(before, agent.q_network_local.parameters()))
+    moved = [float((p.detach() - b).abs().max()) for b, p in zip(tgt_before, agent.q_network_target.parameters())]
+    assert 0 < max(moved) < 0.1                                            # soft update, tau = 0.005
+    assert agent.completed_time == min(tests) and agent.best_state_dict is not None
+    assert 0.01 <= agent.exploration_strategy.epsilon < 1.0                # decayed once per vector pick
+
+
+def test_da3c_and_sac_controller_on_mo_dfjsp(torch_gpu, tmp_path):
+    """HMPSAC end to end on the dynamic environment: three lower-level objective policies trained by the
+    batched double-actor A2C (A3C_v5.{1,2,3}.py), saved/loaded through the reference's checkpoint layout, then
+    the SAC-discrete controller choosing among them (SAC_Discrete.py:197-240)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedMODFJSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.A3C import DA3C
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.SAC_Discrete import SAC_Discrete
+    N = 48
+    test_env = BatchedMODFJSP(_dyn_instances(6, 400), rng_seed=2)
+    rounds = [0]
+
+    def make_train_env():
+        rounds[0] += 1
+        return BatchedMODFJSP(_dyn_instances(N, 1000 * rounds[0]), rng_seed=rounds[0])
+
+    torch.manual_seed(0)
+    for policy in (0, 1, 2):
+        tr = DA3C(make_train_env, test_env, reward_policy=policy, hidden_size=32, hidden_layer=2, seed=policy, max_steps=400)
+        before = [p.detach().clone() for p in tr.actor_machine_model.parameters()]
+        objs = [tr.run_one_round() for _ in range(2)]
+        assert all(np.isfinite(o) and o >= 0 for o in objs) and all(np.isfinite(v) for v in tr.last_losses)
+        assert any(not torch.equal(b, p) for b, p in zip(before, tr.actor_machine_model.parameters()))
+        assert tr.objective_min == min(objs)
+        folder = tmp_path / ("policy_networks_v5.%d" % (policy + 1))
+        folder.mkdir()
+        tr.save_actor_model(str(folder))
+    # the controller loads reference-shaped nets (3 x 200) from that layout: retrain one quickly at that size
+    big = DA3C(make_train_env, test_env, reward_policy=0, seed=9, max_steps=400)
+    for policy in (0, 1, 2):
+        big.save_actor_model(str(tmp_path / ("policy_networks_v5.%d" % (policy + 1))))
+    env = BatchedMODFJSP(_dyn_instances(N, 77), rng_seed=4)
+    sac = SAC_Discrete(env, lower_policies=str(tmp_path), hidden_size=32, hidden_layer=2, seed=1, max_steps=400,
+                       hyper={"min_steps_before_learning": 300, "update_every_n_steps": 200, "batch_size": 128,
+                              "learning_updates_per_learning_session": 2})
+    actor_before = [p.detach().clone() for p in sac.actor_local.parameters()]
+    out = sac.run_n_episodes(2)
+    assert len(out) == 2 and all(np.isfinite(v) and v >= 0 for ep in out for v in ep)
+    assert sac.global_step_number == len(sac.memory) or len(sac.memory) == sac.memory.capacity
+    assert sac.learn_sessions > 0 and all(np.isfinite(v) for v in sac.last_losses)
+    assert any(not torch.equal(b, p) for b, p in zip(actor_before, sac.actor_local.parameters()))
+    assert float(sac.alpha) > 0 and float(sac.alpha) != 1.0                     # entropy temperature was tuned
+    st = env.read()["status"].cpu().numpy()
+    assert ((st & ~4) == 0).all()
+    rw = sac.memory.rewards[:len(sac.memory)]
+    assert bool(torch.isfinite(rw).all()) and float(rw.max()) <= 0.0          # every objective only grows
