@@ -78,6 +78,7 @@ struct Layout {
     uint32_t i_x;       // f64[KP][MP] fluid solution (INPUT)
     uint32_t i_col;     // f64[KP][MP][2] {fluid_unprocessed_rj_arrival_dict, fluid_process_rate_rj_dict} [fluid_tables_kernel]
     uint32_t i_ss;      // f64[8]   static state (MO variant); [7] = fluid_completed_time of the reset-time LP
+    uint32_t i_obs0;    // f64[16]  observation of the reset state (written by reset_kernel, read by the autoreset path)
     uint32_t i_oarr;    // i32[SP]  time_arrive_s_dict                                   (multi-order batches)
     uint32_t i_ocnt;    // u16[SP][RP] count_sr_dict                                     (multi-order batches)
     // MO_DFJSP batches only (MO_DFJSP_instance_read.py:56-93)

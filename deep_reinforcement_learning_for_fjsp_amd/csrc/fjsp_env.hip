@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -168,7 +169,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         L.i_f4 = take(KP * 4, 4); L.i_rsum = take(KP * 8, 8); L.i_tsum = take(KP * 8, 8);
         L.i_due = take(JP * 4, 4); L.i_jinfo = take(JP * 4, 4); L.i_p = take(MP * KP * 2, 4);
         L.i_x = take(MP * KP * 8, 8); L.i_col = take(MP * KP * 16, 16);
-        L.i_ss = take(64, 8);
+        L.i_ss = take(64, 8); L.i_obs0 = take(128, 8);
         L.i_oarr = take((size_t)Smax * 4, 4); L.i_ocnt = take((size_t)Smax * Rmax * 2, 4);
         if (dyn) {
             L.i_pw = take(MP * KP * 2, 4); L.i_ipw = take(MP * 4, 4); L.i_bkoff = take((MP + 1) * 2, 4);
@@ -329,6 +330,18 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         set_error("fluid_tables_kernel launch failed");
         fjsp_env_destroy(e);
         return FJSP_E_HIP;
+    }
+    {
+        // one reset of every env publishes each instance's reset observation (i_obs0, read by the autoreset path
+        // of step_kernel); afterwards every env is marked done again so that step() before reset() is flagged,
+        // like the reference's uninitialised object would fail
+        std::vector<int32_t> ones(N, 1);
+        if (launch_reset(b, nullptr, nullptr, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy2D(b.envs + offsetof(EnvScalars, done), L.e_stride, ones.data(), 4, 4, N, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("initial reset failed");
+            fjsp_env_destroy(e);
+            return FJSP_E_HIP;
+        }
     }
     *out = e;
     return FJSP_OK;

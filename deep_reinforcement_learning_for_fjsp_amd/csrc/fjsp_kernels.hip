@@ -590,30 +590,46 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
     }
 }
 
-// Machine.gap_ave (class_FJSSP.py:144-146) for one machine: serial sum over
-// kind_task_tuple order of unprocessed - fluid_unprocessed, divided by (n + 1e-18).
+// Machine.gap_ave (class_FJSSP.py:144-146) of up to three machines at once: a strictly sequential sum over
+// kind_task_tuple order of unprocessed - fluid_unprocessed of the machine's operation types, divided by
+// (n + 1e-18).  The gap rows of the three machines (ineligible entries +0.0, an exact identity of the
+// running sum) go to the three LDS operand rows and lanes 0..2 walk one row each, so the chains cost one
+// LDS read + one add per element instead of a ballot/readlane walk per machine.  Machine ids < 0 are
+// skipped.  Returns, in lane q < 3, the gap_ave of machine mq.
 template <int KC, int V>
-__device__ __forceinline__ double machine_gap_ave(const W<KC, V> &w, int m) {
+__device__ __forceinline__ double gap_ave3(const W<KC, V> &w, int m0, int m1, int m2) {
     const double dt = fluid_dt(w);
-    double s = 0.0;
-    int n = 0;
+    const int n8 = (w.K + 7) & ~7;
+    const uint32_t src_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.frL) - fjsp_lds) +
+                             (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));
+    int cnt_q[3] = {0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const int k = c * kWave + w.lane;
-        const int o = k * w.MP + m;
-        const int pm = w.p_i[o];
-        double g = 0.0;
-        if (pm > 0) g = w.unp[o] - (w.col_i[2 * o] - dt * w.col_i[2 * o + 1]);
-        uint64_t em = __ballot(pm > 0);
-        n += __builtin_popcountll(em);
-        while (em) {
-            const int l = __builtin_ctzll(em);
-            em &= em - 1;
-            s = s + rld(g, l);
+    for (int q = 0; q < 3; ++q) {
+        const int m = q == 0 ? m0 : (q == 1 ? m1 : m2);
+        double *row = q == 0 ? w.frL : (q == 1 ? w.grL : w.tdL);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = c * kWave + w.lane;
+            int pm = 0;
+            double g = 0.0;
+            if (m >= 0) {
+                const int o = k * w.MP + m;
+                pm = w.p_i[o];
+                if (pm > 0) {
+                    const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
+                    g = w.unp[o] - (ar.x - dt * ar.y);
+                }
+            }
+            row[k] = g;
+            cnt_q[q] += __builtin_popcountll(__ballot(pm > 0));
         }
     }
-    if (V == kDyn) return s / (double)n;             // class_MODFJSP.py:158-159 has no epsilon
-    return s / ((double)n + 1e-18);
+    wave_sync();
+    const double sm = lds_chain_sum(src_off, n8);
+    wave_sync();
+    const int n = w.lane == 0 ? cnt_q[0] : (w.lane == 1 ? cnt_q[1] : cnt_q[2]);
+    if (V == kDyn) return sm / (double)n;             // class_MODFJSP.py:158-159 has no epsilon
+    return sm / ((double)n + 1e-18);
 }
 
 // SO_FJSSP.py:300-322 machine_select.  Candidate lists are visited in CPython's
@@ -659,8 +675,21 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
     };
     auto argmax_gave = [&](const CandList &l) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
+        // gap_ave of every candidate, three per pass, parked in the candidate's machine lane
+        double gave_m = 0.0;
+        uint32_t rest = l.mask;
+        while (rest) {
+            int mq[3] = {-1, -1, -1};
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (rest) { mq[q] = (int)__builtin_ctz(rest); rest &= rest - 1; }
+            const double v = gap_ave3<KC, V>(w, mq[0], mq[1], mq[2]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (mq[q] >= 0 && w.lane == mq[q]) gave_m = rld(v, q);
+        }
         int best = -1; double bv = 0.0;
-        visit(l, [&](int m) { const double v = machine_gap_ave<KC, V>(w, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        visit(l, [&](int m) { const double v = rld(gave_m, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
     auto argmin_lane = [&](const CandList &l, int key) {          // first minimum of a machine-lane integer
@@ -946,37 +975,12 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         // 0..2 walk one row each.  In the step kernel the unprocessed matrix lives in HBM and lane 0 has just
         // updated one element of it, so that store is drained first.
         wave_sync_global();
-        const double dt = fluid_dt(w);
         double gave_m = 0.0;                       // lane m (< M): gap_ave of machine m
         for (int m0 = 0; m0 < M; m0 += 3) {
-            int cnt_q[3] = {0, 0, 0};
+            const double v = gap_ave3<KC, V>(w, m0, m0 + 1 < M ? m0 + 1 : -1, m0 + 2 < M ? m0 + 2 : -1);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int m = m0 + q;
-                double *row = q == 0 ? w.frL : (q == 1 ? w.grL : w.tdL);
-#pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    const int k = c * kWave + w.lane;
-                    int pm = 0;
-                    double g = 0.0;
-                    if (m < M) {
-                        const int o = k * w.MP + m;
-                        pm = w.p_i[o];
-                        if (pm > 0) g = w.unp[o] - (w.col_i[2 * o] - dt * w.col_i[2 * o + 1]);
-                    }
-                    row[k] = g;
-                    cnt_q[q] += __builtin_popcountll(__ballot(pm > 0));
-                }
-            }
-            wave_sync();
-            const double sm = lds_chain_sum(src_off, n8);
-            wave_sync();
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const double v = V == kDyn ? rld(sm, q) / (double)cnt_q[q]               // class_MODFJSP.py:158-159
-                                           : rld(sm, q) / ((double)cnt_q[q] + 1e-18);
-                if (w.lane == m0 + q) gave_m = v;
-            }
+            for (int q = 0; q < 3; ++q)
+                if (w.lane == m0 + q) gave_m = rld(v, q);
         }
         // gap_m_ave / gap_m_std over machines in ascending order (:78-80)
         if (w.lane < (uint32_t)w.KP) w.tdL[w.lane] = w.lane < M ? gave_m : 0.0;
@@ -1041,8 +1045,11 @@ __device__ __forceinline__ void emit_state(W<KC, V> &w, double *state_out, bool 
 }
 
 // SO_FJSSP.py:51-76 reset (fresh-object semantics; class_FJSSP.py:173-244 for one order).
+// cached_obs: the observation of the reset state is a pure function of the instance (clock 0, nothing
+// dispatched); reset_kernel leaves it in the instance record (i_obs0) and the autoreset path of step_kernel
+// takes it from there instead of recomputing it.
 template <int KC, int V>
-__device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, double *state_out) {
+__device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, double *state_out, bool cached_obs) {
     w.t = 0; w.step_count = 0; w.done = 0; w.status = 0;
     w.busy = 0; w.completion = 0; w.completion_last = 0;
     w.tard_done = 0; w.delay_sum = 0;
@@ -1080,7 +1087,13 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
     wave_sync();
     wave_sync_global();       // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
     compute_params<KC, V>(w);
+    if (cached_obs) {
+        w.obs_prev_l = w.lane < w.n_obs ? reinterpret_cast<const double *>(w.ir + b->L.i_obs0)[w.lane] : 0.0;
+        return;
+    }
     observe<KC, V>(w);                      // delay_time_sum_unprocessed is 0-relevant only after a step
+    if (w.env < b->n_inst && w.lane < w.n_obs)          // first environment of its instance: publish the reset observation
+        reinterpret_cast<double *>(b->inst + (size_t)w.inst * b->L.i_stride + b->L.i_obs0)[w.lane] = w.scrL[w.lane];
     emit_state<KC, V>(w, state_out, true);
 }
 
@@ -1215,7 +1228,7 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
     // rng_calls survives a reset (the reference's global `random` state does too)
     w.rng_calls = env_ptr<const EnvScalars>(b, env, 0)->rng_calls;
     w.obs_prev_l = 0.0;
-    init_episode<KC, V>(w, &b, state_out);
+    init_episode<KC, V>(w, &b, state_out, false);
     store_dynamic<KC, V>(w, false);
 }
 
@@ -1249,7 +1262,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t 
             }
             return;
         }
-        init_episode<KC, V>(w, &b, nullptr);
+        init_episode<KC, V>(w, &b, nullptr, true);
     } else {
         compute_params<KC, V>(w);
     }
