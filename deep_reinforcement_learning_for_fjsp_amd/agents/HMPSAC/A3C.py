@@ -29,6 +29,7 @@ from torch.distributions import Categorical
 from torch.optim import Adam
 
 from ..Base_Agent import Base_Agent
+from ..linear import run_layers
 from ... import distributed as fdist
 from ...utilities.data_structures.Config import Config
 
@@ -51,9 +52,7 @@ class TaskPolicyNet(nn.Module):
         self.layers_1 = _mlp(input_size_1, hidden_size, hidden_layer_1, output_size_1)
 
     def forward(self, x):
-        for layer in self.layers_1:
-            x = layer(x)
-        return F.softmax(x, dim=-1)
+        return F.softmax(run_layers(self.layers_1, x), dim=-1)
 
 
 class MachinePolicyNet(nn.Module):
@@ -65,9 +64,7 @@ class MachinePolicyNet(nn.Module):
         self.layers_2 = _mlp(input_size_2, hidden_size, hidden_layer_2, output_size_2)
 
     def forward(self, x):
-        for layer in self.layers_2:
-            x = layer(x)
-        return F.softmax(x, dim=-1)
+        return F.softmax(run_layers(self.layers_2, x), dim=-1)
 
 
 class CriticNet(nn.Module):
@@ -78,9 +75,7 @@ class CriticNet(nn.Module):
         self.layers = _mlp(input_size, hidden_size, hidden_layer, output_size)
 
     def forward(self, x):
-        for layer in self.layers:
-            x = layer(x)
-        return x
+        return run_layers(self.layers, x)
 
 
 def episode_returns(rewards, valid, gamma):

@@ -23,6 +23,7 @@ from torch import nn, optim
 from torch.distributions import Categorical
 
 from ..Base_Agent import Base_Agent
+from ..linear import run_layers
 from ... import distributed as fdist
 
 HYPER = {   # utilities/data_structures/Config.py "MP_PPO"
@@ -44,9 +45,7 @@ class ActorNet(nn.Module):
         self.layers.append(nn.Linear(hidden_size, output_size))
 
     def forward(self, x):
-        for layer in self.layers:
-            x = layer(x)
-        return F.softmax(x, dim=-1)
+        return F.softmax(run_layers(self.layers, x), dim=-1)
 
 
 class CriticNet(nn.Module):
@@ -61,9 +60,7 @@ class CriticNet(nn.Module):
         self.layers.append(nn.Linear(hidden_size, output_size))
 
     def forward(self, x):
-        for layer in self.layers:
-            x = layer(x)
-        return x
+        return run_layers(self.layers, x)
 
 
 # ----------------------------------------------------------------------------- math
@@ -134,9 +131,9 @@ class PPOLearner(object):
     def act(self, states, epsilon=0.0, generator=None):
         """pick_action_and_log_prob (:272-284) for a batch of states [N, S] (f32)."""
         probs = self.actor_new(states)
-        dist = Categorical(probs)
+        dist = Categorical(probs, validate_args=False)      # (the validation syncs with the host: illegal in a graph capture)
         action = dist.sample()
-        if epsilon > 0.0:
+        if torch.is_tensor(epsilon) or epsilon > 0.0:
             u = torch.rand(action.shape, device=action.device, generator=generator)
             rnd = torch.randint(0, self.action_size, action.shape, device=action.device, generator=generator)
             action = torch.where(u <= epsilon, rnd, action)
@@ -181,24 +178,12 @@ class PPOLearner(object):
             old_param.data.copy_(new_param.data)
 
 
-def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action):
-    """One batched episode on `env` with `learner`'s policy + one learning round (MPPPO.py:230-270).
-
-    env.step(action_tensor) must accept what encode_action(flat_action) returns.  Returns
-    (memory, losses): the RolloutBuffer used and (critic_loss, actor_loss)."""
-    from .Buffer import RolloutBuffer
-    hp = learner.hp
-    N, device = env.N, env.device
-    state64 = env.reset().clone()
-    T = max_steps
-    memory = memory_holder.get("memory")
-    if memory is None or memory.T < T or memory.N != N or memory.S != env.state_size:
-        memory = RolloutBuffer(T, N, env.state_size, device=device.index or 0)
-        memory_holder["memory"] = memory
+def _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, check_done):
+    """T vector steps: policy inference, epsilon override, HIP env step, rollout-buffer append (MPPPO.py:245-252).
+    `exploration` is a float (eager) or a 0-dim device tensor (graph capture: no host branch on its value)."""
     memory.clear()
-    old_log_prob = torch.zeros(T, N, device=device)
-    done = torch.zeros(N, dtype=torch.uint8, device=device)
-    pair = torch.zeros(N, 2, dtype=torch.uint8, device=device)
+    state64 = env.reset().clone()
+    done = torch.zeros(env.N, dtype=torch.uint8, device=env.device)
     t = 0
     while t < T:
         active = (done == 0).to(torch.uint8)
@@ -210,8 +195,65 @@ def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encod
         state64 = nxt.clone()
         done = dn.clone()
         t += 1
-        if t % 8 == 0 and bool((done != 0).all()):
+        if check_done and t % 8 == 0 and bool((done != 0).all()):
             break
+
+
+class GraphedRollout(object):
+    """The whole T-step rollout of one (environment batch, learner) pair captured ONCE into a HIP graph and
+    replayed every round: a vector step is a chain of ~20 small launches (MLP, sampling, env kernel, buffer
+    append), and replaying the chain from a graph removes the per-launch host cost that dominates the eager
+    loop (rocprofv3: 31 ms of a 82 ms PPO round at 4096 envs).  The exploration rate lives in a device scalar
+    so that it can change between replays; there is no early exit, every replay plays T steps (finished
+    environments idle, their rows are masked by `valid`)."""
+
+    def __init__(self, env, learner, memory, T, encode_action):
+        self.env, self.learner, self.memory, self.T = env, learner, memory, T
+        dev = env.device
+        self.eps = torch.zeros((), device=dev)
+        self.old_log_prob = torch.zeros(T, env.N, device=dev)
+        self.pair = torch.zeros(env.N, 2, dtype=torch.uint8, device=dev)
+        body = lambda: _rollout_body(env, learner, memory, self.old_log_prob, self.eps, T, encode_action, self.pair, False)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):               # warm-up outside the capture (library handles, allocator)
+            body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="relaxed"):
+            body()
+
+    def run(self, exploration):
+        self.eps.fill_(float(exploration))
+        self.graph.replay()
+        return self.memory, self.old_log_prob
+
+
+def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action, use_graph=False):
+    """One batched episode on `env` with `learner`'s policy + one learning round (MPPPO.py:230-270).
+
+    env.step(action_tensor) must accept what encode_action(flat_action) returns.  Returns
+    (memory, losses): the RolloutBuffer used and (critic_loss, actor_loss)."""
+    from .Buffer import RolloutBuffer
+    hp = learner.hp
+    N, device = env.N, env.device
+    T = max_steps
+    memory = memory_holder.get("memory")
+    if memory is None or memory.T < T or memory.N != N or memory.S != env.state_size:
+        memory = RolloutBuffer(T, N, env.state_size, device=device.index or 0)
+        memory_holder["memory"] = memory
+        memory_holder.pop("graph", None)
+    if use_graph:
+        g = memory_holder.get("graph")
+        if g is None or g.env is not env or g.learner is not learner or g.memory is not memory or g.T != T:
+            g = GraphedRollout(env, learner, memory, T, encode_action)
+            memory_holder["graph"] = g
+        _, old_log_prob = g.run(exploration)
+    else:
+        old_log_prob = torch.zeros(T, N, device=device)
+        pair = torch.zeros(N, 2, dtype=torch.uint8, device=device)
+        _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, True)
     n = len(memory)
     states, actions, _, _, _ = memory.sample()
     valid = memory.valid[:n]
@@ -227,9 +269,10 @@ class PPO(Base_Agent):
     `environment` is a BatchedSOFJSSP; the flat action a in [0, 30) is the rule pair
     (a // 5, a % 5) of SO_FJSSP's [6, 5] action space."""
 
-    def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None):
+    def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None, use_graph=False):
         super().__init__()
         self.environment = environment
+        self.use_graph = use_graph
         self.device = environment.device
         self.state_size = environment.state_size
         self.action_size = environment.actions_size[0] * environment.actions_size[1]
@@ -257,7 +300,7 @@ class PPO(Base_Agent):
         if exploration is None:                                                         # :240-241
             exploration = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])
         memory, losses = collect_and_learn(self.environment, self.learner, self._holder, exploration,
-                                           self.max_steps or 64, self._encode)
+                                           self.max_steps or 64, self._encode, use_graph=self.use_graph)
         self.global_step_number += int(memory.valid[:len(memory)].sum().item())
         self.episode_number += 1
         r = self.environment.read()

@@ -1116,14 +1116,23 @@ __device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a
     const uint32_t idle = ~w.busy & w.mmask;
     const int k_sel = task_select<KC, V>(w, a0, idle);
     STAMP(w, 2);
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 7
+    w.rng_calls += (uint32_t)k_sel; *k_out = k_sel; *m_out = -1; return 0.0;      // diagnostic: stop after task_select
+#endif
     int pm = 0, en_sel = 0;
     double un_sel = 0.0;
     const int m_sel = k_sel >= 0 ? machine_select<KC, V>(w, a1, k_sel, idle, &pm, &un_sel, &en_sel) : -1;
     STAMP(w, 3);
     *k_out = k_sel; *m_out = m_sel;
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 8
+    w.rng_calls += (uint32_t)(k_sel + m_sel + pm); return un_sel;                 // diagnostic: stop after machine_select
+#endif
     if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
     dispatch_and_advance<KC, V>(w, b, k_sel, m_sel, pm, un_sel, en_sel);
     STAMP(w, 4);
+#if defined(FJSP_ABLATE) && FJSP_ABLATE == 9
+    return 0.0;                                                                   // diagnostic: stop after dispatch_and_advance
+#endif
     if (is_mord_v<V> && w.pending) return 0.0;        // an order arrived: the step is finished by arrival_kernel
     return env_step_finish<KC, V>(w, mo, state_out);
 }

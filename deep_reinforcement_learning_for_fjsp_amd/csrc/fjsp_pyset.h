@@ -7,7 +7,8 @@
 //     >= 32 slots where every value < 32 sits in its own slot: ascending order;
 //   * a set of <= 4 elements lives in the initial 8-slot table: slot = v & 7,
 //     collisions re-probe with i = (5 i + 1 + (perturb >>= 5)) & 7 (no linear
-//     probes in an 8-slot table), so the order depends on insertion order;
+//     probes in an 8-slot table), so the order depends on insertion order --
+//     unless every value is < 8, where slot = value and the order is ascending;
 //   * set & set iterates the SMALLER operand (the right one on a tie) in its
 //     table order, keeps members of the other, and inserts them into a fresh set.
 //
@@ -63,6 +64,9 @@ FJSP_HD inline CandList pyset_and(uint32_t a_mask, uint32_t b_mask, uint32_t b_f
     out.packed = 0;
     out.asc = true;
     if (out.n >= 5 || out.n <= 1) return out;
+    // every member of both operands < 8: in an 8-slot table value v sits in slot v (no collision is possible
+    // between distinct values < 8), so every table involved iterates in ascending order
+    if (((a_mask | b_mask) >> 8) == 0) return out;
     const int nA = popc32(a_mask), nB = popc32(b_mask);
     const bool iter_a = nB > nA;                       // set_intersection swaps to iterate the smaller operand
     const uint32_t it_mask = iter_a ? a_mask : b_mask;

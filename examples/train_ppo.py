@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--eager", action="store_true", help="launch every op of the rollout from Python instead of replaying the HIP graph")
     args = ap.parse_args()
     import torch
     from deep_reinforcement_learning_for_fjsp_amd import distributed as fd, instances as fi
@@ -34,7 +35,7 @@ def main():
     insts = fi.InstanceSet(N).generate_range(1000 + rank * N, fi.bench_10x5_params()).solve_fluid()
     env = BatchedSOFJSSP(insts, device=local, rng_seed=7 + rank * N)
     torch.manual_seed(1234 + rank)
-    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=not args.eager)
     agent.run_one_policy_network()          # warm-up round (allocations, kernel caches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -50,8 +50,10 @@ def test_rollout_buffer_append_and_returns(torch_gpu):
         buf.add_experience(*rows[0])        # full
 
 
-def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu):
-    """BASELINE config 3 in miniature: 256 envs, actor/critic 2x128, three learning rounds."""
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu, use_graph):
+    """BASELINE config 3 in miniature: 256 envs, actor/critic 2x128, three learning rounds; eager rollout and the
+    rollout replayed from a captured HIP graph (policy + env kernel + buffer append, MPPPO.GraphedRollout)."""
     torch = torch_gpu
     from deep_reinforcement_learning_for_fjsp_amd import instances as fi
     from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedSOFJSSP
@@ -60,7 +62,7 @@ def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu):
     s = fi.InstanceSet(N).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
     env = BatchedSOFJSSP(s, rng_seed=3)
     torch.manual_seed(0)
-    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=use_graph)
     K = np.array([s.dims(i)["K"] for i in range(N)])
     for rnd in range(3):
         tard, mk, (c_loss, a_loss) = agent.run_one_policy_network()

@@ -143,3 +143,26 @@ def test_data_parallel_round_equals_single_process(tmp_path):
     for a, b, w in zip(r0, r1, want):
         assert torch.equal(a, b)                                   # ranks stay in lock-step
         torch.testing.assert_close(a, w, rtol=2e-4, atol=2e-5)      # == single process up to f32 summation order
+
+
+def test_tall_linear_split_k_weight_gradient():
+    """agents/linear.py: the split-K weight gradient equals autograd's (same f32 products, other summation order)."""
+    import torch
+    from deep_reinforcement_learning_for_fjsp_amd.agents import linear as L
+    torch.manual_seed(0)
+    layer = torch.nn.Linear(20, 16)
+    x = torch.randn(1000, 20, requires_grad=True)
+    up = torch.randn(1000, 16)
+    (layer(x) * up).sum().backward()
+    want = (x.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone())
+    x.grad = None; layer.zero_grad()
+    old = L.CHUNKS
+    L.CHUNKS = 7                      # 1000 = 7 * 142 + 6: exercises the remainder rows
+    try:
+        (L._TallLinear.apply(x, layer.weight, layer.bias) * up).sum().backward()
+    finally:
+        L.CHUNKS = old
+    torch.testing.assert_close(x.grad, want[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(layer.weight.grad, want[1], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(layer.bias.grad, want[2], rtol=1e-4, atol=1e-4)
+    assert L.tall_linear(x, layer).shape == (1000, 16)          # short / CPU batches take the plain layer

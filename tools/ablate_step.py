@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """DIAGNOSTIC ONLY: time step_kernel with phases compiled out (-DFJSP_ABLATE=n; results are wrong by
 construction) to see where a launch's time goes.  0 full | 1 no emit_state | 2 no observe/emit |
-3 loads+compute_params+stores | 4 loads+stores | 5 empty kernel | 6 full without the column gather of machine_select."""
+3 loads+compute_params+stores | 4 loads+stores | 5 empty kernel | 6 full without the column gather of machine_select |
+7 stop after task_select | 8 stop after machine_select | 9 stop after dispatch_and_advance."""
 import os
 import subprocess
 import sys
@@ -32,7 +33,7 @@ for i in range(1000): env.step(acts[i %% 64], autoreset=True)
 e1.record(); torch.cuda.synchronize()
 print("%%.2f us/launch" %% (e0.elapsed_time(e1)))
 ''' % (REPO, N)
-LEVELS = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--level=')] or list(range(6))
+LEVELS = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--level=')] or [5, 4, 3, 7, 8, 9, 2, 1, 0]
 for level in LEVELS:
     out = os.path.join(REPO, "gpurun_out", "libfjsp_ablate%d.so" % level)
     os.makedirs(os.path.dirname(out), exist_ok=True)
