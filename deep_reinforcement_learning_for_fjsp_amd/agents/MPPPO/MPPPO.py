@@ -120,8 +120,9 @@ class PPOLearner(object):
         self.critic = CriticNet(state_size, hidden_size, critic_hidden_layer, 1).to(self.device)
         torch.random.set_rng_state(gen_state)
         Base_Agent.copy_model_over_dict(self.actor_new, self.actor_old)
-        self.actor_optimizer = optim.Adam(self.actor_new.parameters(), lr=self.hp["learning_rate"], eps=1e-4)
-        self.critic_optimizer = optim.Adam(self.critic.parameters(), lr=self.hp["learning_rate"], eps=1e-4)
+        fused = self.device.type == "cuda"       # one multi-tensor kernel per optimiser step instead of one per parameter
+        self.actor_optimizer = optim.Adam(self.actor_new.parameters(), lr=self.hp["learning_rate"], eps=1e-4, fused=fused)
+        self.critic_optimizer = optim.Adam(self.critic.parameters(), lr=self.hp["learning_rate"], eps=1e-4, fused=fused)
         self.action_size = action_size
         self.train_critic = train_critic
         self.actor_bucket = fdist.FlatGradBucket(self.actor_new.parameters())
@@ -147,7 +148,14 @@ class PPOLearner(object):
         actions = actions.reshape(-1)
         old_log_prob = old_log_prob.reshape(-1).detach()
         returns = returns.reshape(-1).detach()
-        m = (valid.reshape(-1) > 0).to(states.dtype)
+        vmask = valid.reshape(-1) > 0
+        if states.is_cuda and states.shape[0] >= (1 << 15):
+            # rows of finished environments carry no sample (up to a third of a [T, N] rollout): drop them once
+            # per round instead of pushing them through every one of the 20 forward/backward passes
+            idx = torch.nonzero(vmask).reshape(-1)
+            states, actions, old_log_prob, returns = states[idx], actions[idx], old_log_prob[idx], returns[idx]
+            vmask = torch.ones(idx.shape[0], dtype=torch.bool, device=states.device)
+        m = vmask.to(states.dtype)
         count = fdist.all_reduce_scalar_sum(m.sum())          # global number of samples
         with torch.no_grad():
             advantages = returns - self.critic(states).squeeze(1)                       # :263
@@ -161,7 +169,7 @@ class PPOLearner(object):
                 self.critic_bucket.all_reduce()
                 torch.nn.utils.clip_grad_norm_(self.critic.parameters(), hp["gradient_clipping_norm"])
                 self.critic_optimizer.step()
-            new_log_prob = Categorical(self.actor_new(states)).log_prob(actions)
+            new_log_prob = Categorical(self.actor_new(states), validate_args=False).log_prob(actions)
             terms = actor_loss_terms(new_log_prob, old_log_prob, advantages, hp["clip_epsilon"])
             a_loss = -(terms * m).sum() / count                                         # -torch.mean(...), :351
             self.actor_optimizer.zero_grad()
