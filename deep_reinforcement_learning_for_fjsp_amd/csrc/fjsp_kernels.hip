@@ -897,23 +897,47 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
 template <int KC, int V>
 __device__ __forceinline__ long long observe(W<KC, V> &w) {
     const int K = w.K, M = w.M;
-    // ---- integer statistics (order-free): packed DPP reductions (totals < 65536, checked at create)
-    uint32_t nun_s = 0, a_s = 0, e_s = 0, ja_s = 0, je_s = 0;
-    long long tu = 0;
+    bool single_job = true;      // every operation type has exactly one job (10x5, Mk01..10): counts are 0 or 1
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const bool last = ((w.kB[c] >> 24) & 1u) != 0;
-        nun_s += (uint32_t)w.nun[c]; a_s += (uint32_t)w.cnt_a[c]; e_s += (uint32_t)w.cnt_e[c];
-        if (last) { ja_s += (uint32_t)w.cnt_a[c]; je_s += (uint32_t)w.cnt_e[c]; tu += w.tard[c]; }
+    for (int c = 0; c < KC; ++c) single_job = single_job && !is_mord_v<V> && __ballot((w.kA[c] >> 16) > 1u) == 0;
+    // ---- integer statistics (order-free)
+    int task_number = 0, delay_a = 0, delay_e = 0, job_a = 0, job_e = 0;
+    const int job_number = w.n_unassigned;
+    long long tard_unproc;
+    if (single_job && w.t < (1 << 22)) {
+        // 0/1 counts: ballots + scalar popcounts; the tardiness of the (at most 64 KC) late last-stage
+        // operations fits one 32-bit DPP reduction
+        int tl = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const bool last = ((w.kB[c] >> 24) & 1u) != 0;
+            task_number += __builtin_popcountll(__ballot(w.nun[c] > 0));
+            delay_a += __builtin_popcountll(__ballot(w.cnt_a[c] > 0));
+            delay_e += __builtin_popcountll(__ballot(w.cnt_e[c] > 0));
+            job_a += __builtin_popcountll(__ballot(last && w.cnt_a[c] > 0));
+            job_e += __builtin_popcountll(__ballot(last && w.cnt_e[c] > 0));
+            tl += last ? w.tard[c] : 0;
+        }
+        tard_unproc = (long long)wave_sum(tl);
+    } else {
+        // packed DPP reductions (totals < 65536, checked at create)
+        uint32_t nun_s = 0, a_s = 0, e_s = 0, ja_s = 0, je_s = 0;
+        long long tu = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const bool last = ((w.kB[c] >> 24) & 1u) != 0;
+            nun_s += (uint32_t)w.nun[c]; a_s += (uint32_t)w.cnt_a[c]; e_s += (uint32_t)w.cnt_e[c];
+            if (last) { ja_s += (uint32_t)w.cnt_a[c]; je_s += (uint32_t)w.cnt_e[c]; tu += w.tard[c]; }
+        }
+        const uint32_t r1 = (uint32_t)wave_sum((int)(nun_s | (a_s << 16)));
+        const uint32_t r2 = (uint32_t)wave_sum((int)(e_s | (ja_s << 16)));
+        const uint32_t r3 = (uint32_t)wave_sum((int)(je_s | ((uint32_t)(tu >> 24) << 16)));
+        const uint32_t r4 = (uint32_t)wave_sum((int)(tu & 0xFFFFFF));
+        task_number = (int)(r1 & 0xFFFFu); delay_a = (int)(r1 >> 16);
+        delay_e = (int)(r2 & 0xFFFFu); job_a = (int)(r2 >> 16);
+        job_e = (int)(r3 & 0xFFFFu);
+        tard_unproc = (long long)r4 + ((long long)(r3 >> 16) << 24);
     }
-    const uint32_t r1 = (uint32_t)wave_sum((int)(nun_s | (a_s << 16)));
-    const uint32_t r2 = (uint32_t)wave_sum((int)(e_s | (ja_s << 16)));
-    const uint32_t r3 = (uint32_t)wave_sum((int)(je_s | ((uint32_t)(tu >> 24) << 16)));
-    const uint32_t r4 = (uint32_t)wave_sum((int)(tu & 0xFFFFFF));
-    const int task_number = (int)(r1 & 0xFFFFu), delay_a = (int)(r1 >> 16);
-    const int delay_e = (int)(r2 & 0xFFFFu), job_a = (int)(r2 >> 16);
-    const int job_e = (int)(r3 & 0xFFFFu), job_number = w.n_unassigned;
-    const long long tard_unproc = (long long)r4 + ((long long)(r3 >> 16) << 24);
     // ---- the three mean / population-std pairs (:84-95).  Lane 0 walks finish_rate, lane 1 gap_rate,
     // lane 2 the machines' time_end (an exact integer sum, so the f64 walk equals sum(int)/M, :384-385);
     // the squared deviations are formed lane-parallel between the two walks so the second walk is a
@@ -923,10 +947,7 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
     const uint32_t src_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.frL) - fjsp_lds) +
                              (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));
     const double len = w.lane == 2 ? (double)M : (double)K;
-    double frv[KC], grv[KC];
-    bool single_job = true;      // every operation type has exactly one job: the divisions below are x / 1.0 == x
-#pragma unroll
-    for (int c = 0; c < KC; ++c) single_job = single_job && !is_mord_v<V> && __ballot((w.kA[c] >> 16) > 1u) == 0;
+    double frv[KC], grv[KC];                  // with single_job the divisions below are x / 1.0 == x
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int tot = w.tot[c];
@@ -942,8 +963,14 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         w.tdL[k] = (c == 0 && w.lane < M) ? (double)w.tend_m : 0.0;
     }
     wave_sync();
-    const double ave = lds_chain_sum(src_off, n8) / len;
+    // one division for the three means (lanes 0..2) and the four delay ratios of :156-165 (lanes 4..7:
+    // (delay_a, delay_e) / task_number, (job_a, job_e) / job_number)
+    const int rnum = w.lane == 4 ? delay_a : (w.lane == 5 ? delay_e : (w.lane == 6 ? job_a : job_e));
+    const int rden = w.lane < 6 ? task_number : job_number;
+    const double csum = lds_chain_sum(src_off, n8);
+    const double ave = (w.lane < 4 ? csum : (double)rnum) / (w.lane < 4 ? len : (double)rden);
     const double ave_fr = rld(ave, 0), ave_gr = rld(ave, 1), ave_td = rld(ave, 2);
+    const double ratio = w.done ? 0.0 : ave;             // lanes 4..7
     wave_sync();
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -993,16 +1020,13 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         wave_sync();
         const double gm_std = sqrt(lds_chain_sum(td_off, m8) / (double)M);
         if (V == kDyn) {
-            const int num = w.lane == 0 ? delay_a : (w.lane == 1 ? delay_e : (w.lane == 2 ? job_a : job_e));
-            const int den = w.lane < 2 ? task_number : job_number;
-            const double ratio = w.done ? 0.0 : (double)num / (double)den;       // :176-185
             wave_sync();
             if (w.lane == 0) {
                 w.scrL[0] = w.sstate[0]; w.scrL[1] = (double)M; w.scrL[2] = (double)w.n_orders; w.scrL[3] = ct_std;
                 w.scrL[4] = ratio_idle; w.scrL[5] = cro_ave; w.scrL[6] = cro_std; w.scrL[7] = gap_ave; w.scrL[8] = gap_std;
                 w.scrL[9] = gm_ave; w.scrL[10] = gm_std;
             }
-            if (w.lane < 4) w.scrL[11 + w.lane] = ratio;
+            if (w.lane >= 4 && w.lane < 8) w.scrL[7 + w.lane] = ratio;                    // :176-185
             wave_sync();
             return tard_unproc;
         }
@@ -1013,18 +1037,13 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         wave_sync();
         return 0;          // this subclass never calls update_parameter: delay_time_sum_unprocessed stays 0
     }
-    // the four delay ratios (:156-165): one division, lanes 0..3 carry (delay_a, delay_e) / task_number and
-    // (job_a, job_e) / job_number
-    const int num = w.lane == 0 ? delay_a : (w.lane == 1 ? delay_e : (w.lane == 2 ? job_a : job_e));
-    const int den = w.lane < 2 ? task_number : job_number;
-    const double ratio = w.done ? 0.0 : (double)num / (double)den;
     const int o0 = is_so_v<V> ? 1 : 0;
     if (w.lane == 0) {
         if (is_so_v<V>) w.scrL[0] = (double)M;
         w.scrL[o0] = ct_std; w.scrL[o0 + 1] = cro_ave; w.scrL[o0 + 2] = cro_std; w.scrL[o0 + 3] = gap_ave;
         w.scrL[o0 + 4] = gap_std;
     }
-    if (w.lane < 4) w.scrL[o0 + 5 + w.lane] = ratio;
+    if (w.lane >= 4 && w.lane < 8) w.scrL[o0 + 1 + w.lane] = ratio;
     wave_sync();
     return tard_unproc;
 }
