@@ -144,3 +144,63 @@ def test_a2c_returns_and_losses_per_episode():
         live += 1
     assert math.isclose(float(c), wc / live, rel_tol=1e-9)
     assert math.isclose(float(lt), wt / live, rel_tol=1e-9) and math.isclose(float(lm), wm / live, rel_tol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel updates (world_size 2 over gloo): every rank holds its own replay shard, the flat
+# gradient of each network is all-reduced once per optimiser step
+class _Dev(object):
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.N = 4
+
+
+def _offpolicy_worker(rank, world, port, tmp):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.SAC_Discrete import SAC_Discrete
+    from deep_reinforcement_learning_for_fjsp_amd.agents.DDQN.DDQN import DDQN
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = torch.load(os.path.join(tmp, "data.pt"))
+    B = data["s"].shape[0] // world
+    sl = slice(rank * B, (rank + 1) * B)
+    hp = {"batch_size": B, "buffer_size": 64}
+    sac = SAC_Discrete(_Dev(), hidden_size=16, hidden_layer=2, hyper=hp, seed=3)
+    sac.memory.add_batch(data["s"][sl], data["a3"][sl], data["r"][sl], data["n"][sl], data["d"][sl])
+    sac.learn()
+    dq = DDQN(None, _Dev(), hidden_size=16, hidden_layer=2, hyper=dict(hp, learning_rate=1e-2), seed=4)
+    dq.learn(experiences=(data["s18"][sl], data["a20"][sl], data["r"][sl], data["n18"][sl], data["d"][sl]))
+    out = [p.detach() for net in (sac.critic_local, sac.critic_local_2, sac.actor_local, dq.q_network_local) for p in net.parameters()]
+    out.append(sac.log_alpha.detach())
+    torch.save(out, os.path.join(tmp, "off_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_offpolicy_updates_stay_in_lock_step_over_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.SAC_Discrete import SAC_Discrete
+    torch.manual_seed(2)
+    B2 = 24
+    data = dict(s=torch.randn(B2, 30), n=torch.randn(B2, 30), s18=torch.randn(B2, 18), n18=torch.randn(B2, 18),
+                a3=torch.randint(0, 3, (B2, 1)).float(), a20=torch.randint(0, 20, (B2, 1)).float(),
+                r=-torch.rand(B2, 1), d=(torch.rand(B2, 1) < 0.2).float())
+    torch.save(data, str(tmp_path / "data.pt"))
+    # single process on the whole batch (the SAC nets have no batch statistics, so the sharded update must agree)
+    sac = SAC_Discrete(_Dev(), hidden_size=16, hidden_layer=2, hyper={"batch_size": B2, "buffer_size": 64}, seed=3)
+    sac.memory.add_batch(data["s"], data["a3"], data["r"], data["n"], data["d"])
+    sac.learn()
+    want = [p.detach() for net in (sac.critic_local, sac.critic_local_2) for p in net.parameters()]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_offpolicy_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "off_rank0.pt"))
+    r1 = torch.load(str(tmp_path / "off_rank1.pt"))
+    assert len(r0) == len(r1)
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)                                    # identical parameters on both ranks after the step
+    for a, w in zip(r0, want):
+        torch.testing.assert_close(a, w, rtol=2e-4, atol=2e-5)      # critics == single-process update on the union batch
