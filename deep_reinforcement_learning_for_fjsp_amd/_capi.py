@@ -82,6 +82,11 @@ def lib():
         raise ImportError(
             "%s is missing: the HIP extension is the product and there is no fallback. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repo root." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64; the process must hold ONE HIP runtime, the one torch's device
+    # tensors and streams belong to.  Importing torch first makes the loader resolve this library's HIP
+    # symbols against that runtime (loaded the other way round, the system runtime under /opt/rocm comes
+    # up next to torch's and sees no device).
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
