@@ -149,13 +149,18 @@ __device__ __forceinline__ int wave_min(int v) {
     v = min(v, DPP(v, 0x140, 0x7fffffff));
     return min(min(rl(v, 0), rl(v, 16)), min(rl(v, 32), rl(v, 48)));
 }
+// a[c] for a wave-uniform chunk index, written as selects between VALUES: the optimiser turns some
+// spellings of this into an indexed load, which pins the whole wave state in scratch (checked per chunk
+// count with -Rpass-analysis=kernel-resource-usage: every kernel must report ScratchSize 0)
 template <int KC, class T>
 __device__ __forceinline__ T pick(const T (&a)[KC], int c) {
-    T r = a[0];
-#pragma unroll
-    for (int i = 1; i < KC; ++i)
-        if (c == i) r = a[i];
-    return r;
+    if constexpr (KC == 1) return a[0];
+    else if constexpr (KC == 2) { T r = a[0]; if (c == 1) r = a[1]; return r; }
+    else {
+        static_assert(KC == 4, "chunk counts are 1, 2 or 4");
+        const T lo = (c & 1) ? a[1] : a[0], hi = (c & 1) ? a[3] : a[2];
+        return (c & 2) ? hi : lo;
+    }
 }
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;
@@ -688,21 +693,21 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         if (V == kDyn) en = pm * (int)w.pw_i[o];                 // energy_mrj_dict class_MODFJSP.py:178
 #endif
     }
-    auto visit = [&](const CandList &l, auto &&f) {
+    auto visit = [&](const CandList &l, auto &&f) __attribute__((always_inline)) {
         if (l.asc) { uint32_t m = l.mask; while (m) { f((int)__builtin_ctz(m)); m &= m - 1; } }
         else for (int i = 0; i < l.n; ++i) f((int)((l.packed >> (8 * i)) & 0xFFu));
     };
-    auto argmax_gap = [&](const CandList &l) {
+    auto argmax_gap = [&](const CandList &l) __attribute__((always_inline)) {
         int best = -1; double bv = 0.0;
-        visit(l, [&](int m) { const double v = rld(g, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(g, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
-    auto argmin_p = [&](const CandList &l) {
+    auto argmin_p = [&](const CandList &l) __attribute__((always_inline)) {
         int best = -1, bv = 0;
-        visit(l, [&](int m) { const int v = rl(pm, m); if (best < 0 || v < bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(pm, m); if (best < 0 || v < bv) { bv = v; best = m; } });
         return best;
     };
-    auto argmax_gave = [&](const CandList &l) {
+    auto argmax_gave = [&](const CandList &l) __attribute__((always_inline)) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
         // gap_ave of every candidate, three per pass, parked in the candidate's machine lane
         double gave_m = 0.0;
@@ -718,12 +723,12 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
                 if (mq[q] >= 0 && w.lane == mq[q]) gave_m = rld(v, q);
         }
         int best = -1; double bv = 0.0;
-        visit(l, [&](int m) { const double v = rld(gave_m, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(gave_m, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
-    auto argmin_lane = [&](const CandList &l, int key) {          // first minimum of a machine-lane integer
+    auto argmin_lane = [&](const CandList &l, int key) __attribute__((always_inline)) {          // first minimum of a machine-lane integer
         int best = -1, bv = 0;
-        visit(l, [&](int m) { const int v = rl(key, m); if (best < 0 || v < bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(key, m); if (best < 0 || v < bv) { bv = v; best = m; } });
         return best;
     };
     int m_sel;
@@ -1290,7 +1295,8 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
 }
 
 template <int KC, int V>
-__global__ __launch_bounds__(256, 4) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
+// (four chunks of per-lane operation state do not fit 128 VGPRs: K > 128 runs at half the occupancy instead of spilling)
+__global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
                                                       double *state_out, double *reward_out, uint8_t *done_out,
                                                       int16_t *trace_km) {
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
@@ -1383,7 +1389,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t 
 // fluid LP of the env's live state (class_FJSSP.py:239) and left x in the env record; this kernel runs
 // update_fluid_parameter (:282-306) for that env, then the second half of step().
 template <int KC, int V>
-__global__ __launch_bounds__(256, 4) void arrival_kernel(DevBatch b, const double *mo, int n_pending, double *state_out,
+__global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void arrival_kernel(DevBatch b, const double *mo, int n_pending, double *state_out,
                                                          double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     const int wave = uni((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * (blockDim.x >> 6) + wave;
