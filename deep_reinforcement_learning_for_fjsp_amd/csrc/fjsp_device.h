@@ -98,7 +98,6 @@ struct Layout {
     uint32_t e_rsum;    // f64[KP]
     uint32_t e_tsum;    // f64[KP]
     uint32_t e_col;     // f64[KP][MP][2]
-    uint32_t e_xin;     // f64[KP][MP] fluid solution of the pending LP, written by the host service
     uint32_t e_dyn;     // MO_DFJSP batches only: DynScalars, then i32[MP] time_end of the machine's last task (-1 = none)
     uint32_t e_lpq;     // u16[2][KP] LP inputs of the pending arrival: Q[k], n_now[k]; then i16[2] stashed (k, m) of the step
 };
@@ -106,7 +105,9 @@ struct Layout {
 struct DevBatch {
     int32_t N, n_inst, KC, KP, MP, JP, variant, n_obs, n_static, state_size;
     int32_t mord, SP, RP;    // multi-order batch (S > 1): order / kind paddings of i_oarr, i_ocnt
-    uint32_t *pending_count; // number of envs that stopped at an order arrival in the last launch (multi-order)
+    uint32_t *pending_count; // [0] number of envs parked at an order arrival by the last launch, [1 + slot] their env ids
+    uint16_t *lp_in;         // [slot][2][KP] LP inputs (Q, n_now) of the parked env in that slot (written when it parks)
+    double *lp_x;            // [slot][KP][MP] fluid solution of that LP (uploaded by the host service, read by arrival_kernel)
     uint64_t rng_seed;
     unsigned char *inst;     // [n_inst] instance records
     unsigned char *envs;     // [N] env records

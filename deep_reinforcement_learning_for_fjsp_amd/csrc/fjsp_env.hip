@@ -5,6 +5,8 @@
 
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstddef>
 #include <cstring>
 #include <mutex>
@@ -30,11 +32,65 @@ struct fjsp_env {
     // multi-order service (host LP at order arrivals)
     const fjsp_instances *src = nullptr;
     int first = 0;
-    std::vector<uint32_t> h_pending;
-    std::vector<uint16_t> h_lpq;
-    std::vector<double> h_xin;
-    int lp_threads = 0;         // 0 = all host cores
+    // pinned host staging of the service: [0] = count, then env ids | LP inputs per slot | solutions per slot
+    uint32_t *h_pending = nullptr;
+    uint16_t *h_lp_in = nullptr;
+    double *h_lp_x = nullptr;
+    int lp_threads = 0;         // 0 = default (min(host cores, 16))
     int64_t lp_solves = 0;      // order-arrival LPs solved so far
+    struct LpPool *pool = nullptr;
+};
+
+// Persistent worker threads of the order-arrival LP service: run(n, fn) calls fn(q) for q in [0, n) on the
+// workers and the caller, returning when all are done.
+struct LpPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(uint32_t)> fn;
+    std::atomic<uint32_t> next{0};
+    uint32_t n = 0, generation = 0;
+    int active = 0;
+    bool stop = false;
+
+    explicit LpPool(int n_workers) {
+        for (int t = 0; t < n_workers; ++t) workers.emplace_back([this] { loop(); });
+    }
+    ~LpPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void drain() {
+        for (;;) {
+            const uint32_t q = next.fetch_add(1);
+            if (q >= n) return;
+            fn(q);
+        }
+    }
+    void loop() {
+        uint32_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            drain();
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    void run(uint32_t count, std::function<void(uint32_t)> f) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            fn = std::move(f); n = count; next.store(0); active = (int)workers.size(); ++generation;
+        }
+        cv_work.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
 };
 
 namespace {
@@ -180,7 +236,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(MP * KP * 8, 8);
         if (b.mord) {
             L.e_q0 = take(KP * 4, 4); L.e_fmask = take(KP * 4, 4); L.e_rsum = take(KP * 8, 8); L.e_tsum = take(KP * 8, 8);
-            L.e_col = take(MP * KP * 16, 16); L.e_xin = take(MP * KP * 8, 8); L.e_lpq = take(KP * 4 + 8, 4);
+            L.e_col = take(MP * KP * 16, 16); L.e_lpq = take(KP * 4 + 8, 4);
         }
         if (dyn) L.e_dyn = take(sizeof(DynScalars) + MP * 4, 8);
         L.e_stride = (uint32_t)((o + 255) / 256 * 256);
@@ -314,6 +370,17 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             if (!hip_ok(hipMalloc(&pp, (N + 1) * 4), "hipMalloc pending list") || !hip_ok(hipMemset(pp, 0, (N + 1) * 4), "hipMemset")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
             e->allocs.push_back(pp);
             b.pending_count = reinterpret_cast<uint32_t *>(pp);
+            // staging of the LP service, one slot per env (worst case: every env parks in the same launch)
+            void *pin = nullptr, *px = nullptr;
+            if (!hip_ok(hipMalloc(&pin, N * 2 * KP * 2), "hipMalloc LP inputs") || (e->allocs.push_back(pin), false) ||
+                !hip_ok(hipMalloc(&px, N * KP * MP * 8), "hipMalloc LP solutions") || (e->allocs.push_back(px), false) ||
+                !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_pending), (N + 1) * 4, hipHostMallocDefault), "hipHostMalloc") ||
+                !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_lp_in), N * 2 * KP * 2, hipHostMallocDefault), "hipHostMalloc") ||
+                !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&e->h_lp_x), N * KP * MP * 8, hipHostMallocDefault), "hipHostMalloc")) {
+                fjsp_env_destroy(e); return FJSP_E_HIP;
+            }
+            b.lp_in = reinterpret_cast<uint16_t *>(pin);
+            b.lp_x = reinterpret_cast<double *>(px);
         }
         b.inst = reinterpret_cast<unsigned char *>(pi);
         b.envs = reinterpret_cast<unsigned char *>(pe);
@@ -352,7 +419,11 @@ void fjsp_env_destroy(fjsp_env *e) {
     {
         DeviceGuard guard(e->device);
         for (void *p : e->allocs) (void)hipFree(p);
+        if (e->h_pending) (void)hipHostFree(e->h_pending);
+        if (e->h_lp_in) (void)hipHostFree(e->h_lp_in);
+        if (e->h_lp_x) (void)hipHostFree(e->h_lp_x);
     }
+    delete e->pool;
     delete e;
 }
 
@@ -374,66 +445,53 @@ namespace {
 int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace,
                      hipStream_t st) {
     const DevBatch &b = e->b;
-    uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, b.pending_count, 4, hipMemcpyDeviceToHost, st));
+    // (the sync below also orders this call after the previous call's solution upload, so the pinned staging
+    // buffers are free again)
+    HIP_TRY(hipMemcpyAsync(e->h_pending, b.pending_count, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t n = e->h_pending[0];
     if (n == 0) return FJSP_OK;
-    e->h_pending.resize(n);
-    HIP_TRY(hipMemcpy(e->h_pending.data(), b.pending_count + 1, (size_t)n * 4, hipMemcpyDeviceToHost));
     const size_t KP = (size_t)b.KP, MP = (size_t)b.MP;
-    // LP inputs of every parked env in one strided copy each way (a parked env's record is not touched by
-    // anything else until arrival_kernel runs)
-    e->h_lpq.resize((size_t)n * 2 * KP);
-    e->h_xin.assign((size_t)n * KP * MP, 0.0);
-    for (uint32_t q = 0; q < n; ++q)
-        HIP_TRY(hipMemcpyAsync(e->h_lpq.data() + (size_t)q * 2 * KP, b.envs + (size_t)e->h_pending[q] * b.L.e_stride + b.L.e_lpq,
-                               2 * KP * 2, hipMemcpyDeviceToHost, st));
+    // env ids and LP inputs of every parked env: two copies, whatever n is (step_kernel packed them by slot)
+    HIP_TRY(hipMemcpyAsync(e->h_pending + 1, b.pending_count + 1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(e->h_lp_in, b.lp_in, (size_t)n * 2 * KP * 2, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     // one LP per parked env, independent: spread over the host cores
-    std::atomic<uint32_t> next{0};
     std::atomic<int> fail{0};
     std::string err;
     std::mutex err_mu;
-    auto work = [&]() {
-        std::vector<int> Q, now;
-        std::vector<double> xk;
-        for (;;) {
-            const uint32_t q = next.fetch_add(1);
-            if (q >= n || fail.load()) return;
-            const int env = (int)e->h_pending[q];
-            const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
-            const uint16_t *lpq = e->h_lpq.data() + (size_t)q * 2 * KP;
-            Q.assign(in.K, 0); now.assign(in.K, 0);
-            for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
-            xk.assign((size_t)in.K * in.M, 0.0);
-            double obj = 0.0;
-            if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) {
-                std::lock_guard<std::mutex> g(err_mu);
-                if (fail.fetch_add(1) == 0) err = fjsp_last_error();     // thread-local message of this worker
-                return;
-            }
-            double *xin = e->h_xin.data() + (size_t)q * KP * MP;
-            for (int k = 0; k < in.K; ++k)
-                for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
+    auto solve_one = [&](uint32_t q) {
+        if (fail.load()) return;
+        const int env = (int)e->h_pending[1 + q];
+        const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
+        const uint16_t *lpq = e->h_lp_in + (size_t)q * 2 * KP;
+        std::vector<int> Q(in.K), now(in.K);
+        for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
+        std::vector<double> xk((size_t)in.K * in.M, 0.0);
+        double obj = 0.0;
+        if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (fail.fetch_add(1) == 0) err = fjsp_last_error();     // thread-local message of this worker
+            return;
         }
+        double *xin = e->h_lp_x + (size_t)q * KP * MP;
+        std::fill(xin, xin + KP * MP, 0.0);
+        for (int k = 0; k < in.K; ++k)
+            for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
     };
-    int n_threads = e->lp_threads > 0 ? e->lp_threads : (int)std::thread::hardware_concurrency();
+    int n_threads = e->lp_threads > 0 ? e->lp_threads : std::min((int)std::thread::hardware_concurrency(), 16);
     if (n_threads <= 0) n_threads = 1;
-    if ((uint32_t)n_threads > n) n_threads = (int)n;
-    if (n_threads == 1) work();
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
-        for (auto &t : th) t.join();
+    if (n_threads == 1 || n == 1) {
+        for (uint32_t q = 0; q < n; ++q) solve_one(q);
+    } else {
+        if (e->pool && (int)e->pool->workers.size() != n_threads - 1) { delete e->pool; e->pool = nullptr; }
+        if (!e->pool) e->pool = new LpPool(n_threads - 1);
+        e->pool->run(n, solve_one);
     }
     if (fail.load()) { set_error(err); return FJSP_E_LP; }
-    for (uint32_t q = 0; q < n; ++q)
-        HIP_TRY(hipMemcpyAsync(b.envs + (size_t)e->h_pending[q] * b.L.e_stride + b.L.e_xin, e->h_xin.data() + (size_t)q * KP * MP,
-                               KP * MP * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b.lp_x, e->h_lp_x, (size_t)n * KP * MP * 8, hipMemcpyHostToDevice, st));
     if (launch_arrival(b, d_mo, (int)n, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
     HIP_TRY(hipMemsetAsync(b.pending_count, 0, 4, st));
-    // the staging buffers are reused by the next service call: the uploads must have left the host
-    HIP_TRY(hipStreamSynchronize(st));
     e->lp_solves += n;
     return FJSP_OK;
 }

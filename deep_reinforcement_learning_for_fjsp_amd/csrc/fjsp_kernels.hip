@@ -1342,9 +1342,16 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
         if (w.lane == 0) {
             int16_t *stash = reinterpret_cast<int16_t *>(w.er + b.L.e_lpq) + 2 * b.KP;
             stash[0] = (int16_t)k_sel; stash[1] = (int16_t)m_sel;
-            const uint32_t slot = atomicAdd(b.pending_count, 1u);
-            b.pending_count[1 + slot] = (uint32_t)env;
         }
+        // take a slot of the service's staging area and leave the LP inputs there: the host fetches the
+        // inputs of all parked envs with one copy
+        uint32_t slot = 0;
+        if (w.lane == 0) { slot = atomicAdd(b.pending_count, 1u); b.pending_count[1 + slot] = (uint32_t)env; }
+        slot = uniu(slot);
+        wave_sync_global();
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(w.er + b.L.e_lpq);     // u16[2][KP] as KP words
+        uint32_t *dst = reinterpret_cast<uint32_t *>(b.lp_in + (size_t)slot * 2 * b.KP);
+        for (int i = w.lane; i < b.KP; i += kWave) dst[i] = src[i];
         store_dynamic<KC, V>(w, false);
         return;
     }
@@ -1398,7 +1405,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void arrival_kernel(DevBatch 
     W<KC, V> w;
     open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
     const Layout &L = b.L;
-    const double *xin = reinterpret_cast<const double *>(w.er + L.e_xin);
+    const double *xin = b.lp_x + (size_t)idx * b.KP * b.MP;
     const uint16_t *lpq = reinterpret_cast<const uint16_t *>(w.er + L.e_lpq);
     double *col = reinterpret_cast<double *>(w.er + L.e_col);
 #pragma unroll

@@ -21,6 +21,22 @@
 namespace fjsp {
 
 namespace {
+// rowi[j] -= f * rowr[j]: the inner loop of a pivot (one rounding for the product, one for the difference:
+// the file is compiled with -ffp-contract=off and the AVX2 clone is built WITHOUT the fma feature, so both
+// clones perform the same IEEE operations element by element and produce identical bits).
+#if defined(__HIP_DEVICE_COMPILE__)      // (hipcc also runs its device pass over this host-only file)
+#define FJSP_HOST_CLONES
+#else
+#define FJSP_HOST_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+FJSP_HOST_CLONES
+void row_axpy(double *__restrict rowi, const double *__restrict rowr, double f, int n) {
+    for (int j = 0; j < n; ++j) rowi[j] -= f * rowr[j];
+}
+FJSP_HOST_CLONES
+void row_scale(double *__restrict row, double piv, int n) {
+    for (int j = 0; j < n; ++j) row[j] /= piv;
+}
 constexpr double kEpsCost = 1e-9;   // entering threshold on reduced cost
 constexpr double kEpsPiv = 1e-9;    // minimum pivot element
 constexpr double kEpsZero = 1e-11;  // |x| below this is reported as exactly 0 (x != 0 test, :290)
@@ -112,20 +128,20 @@ int solve_fluid_lp(int R, int M, const int *Jr, const int *p, const int *Q, cons
         // pivot
         double piv = at(r, s);
         double *rowr = &T[(size_t)r * nc];
-        for (int j = 0; j < nc; ++j) rowr[j] /= piv;
+        row_scale(rowr, piv, nc);
         rowr[s] = 1.0;
         for (int i = 0; i < nr; ++i) {
             if (i == r) continue;
             double f = at(i, s);
             if (f == 0.0) continue;
             double *rowi = &T[(size_t)i * nc];
-            for (int j = 0; j < nc; ++j) rowi[j] -= f * rowr[j];
+            row_axpy(rowi, rowr, f, nc);
             rowi[s] = 0.0;
             if (rowi[rhs] < 0.0 && rowi[rhs] > -1e-12) rowi[rhs] = 0.0;
         }
         double f = z[s];
         if (f != 0.0) {
-            for (int j = 0; j < nc; ++j) z[j] -= f * rowr[j];
+            row_axpy(z.data(), rowr, f, nc);
             z[s] = 0.0;
         }
         basis[r] = s;

@@ -195,7 +195,7 @@ int fjsp_pyset_and_order(uint32_t idle_mask, const int32_t *machines, int32_t n,
 /* HBM bytes the step kernel reads+writes per env-step (algorithmic). */
 int64_t fjsp_env_step_bytes(const fjsp_env *e);
 /* Order arrivals (SO_FJSSP.py:218-231) re-solve the fluid LP on the host, one LP per arriving env, spread
- * over n_threads host threads (0 = all cores; default).  fjsp_env_lp_solves: LPs solved so far. */
+ * over n_threads host threads (0 = default: min(host cores, 16)).  fjsp_env_lp_solves: LPs solved so far. */
 int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads);
 int64_t fjsp_env_lp_solves(const fjsp_env *e);
 
