@@ -268,3 +268,81 @@ def test_device_pyset_order_matches_cpython(built):
             idle = [m for m in range(10) if mask >> m & 1] + ([12, 15, 16, 20, 23, 24, 31] if mask & 1 else [])
             idle = sorted(set(idle))
             assert order(idle, elig, False) == list(set(idle) & set(elig)), (idle, elig)
+
+
+def test_mo_dfjsp_machine_data_loader_and_create_checks(built, tmp_path):
+    """MO_DFJSP_instance_read.py:56-93 through the product loader: the power column of process_data.csv, idle power
+    and breakdown windows of machine_data.csv (one row per window, first row of a machine sets its idle power),
+    the set/get ABI round trip, and the create-time checks of the dynamic variant."""
+    import csv
+    from deep_reinforcement_learning_for_fjsp_amd import _capi, instances as fi
+    insts, _, _ = H.load_suite("mo_dfjsp")
+    a = next(x for x in insts if x.name.startswith("gen"))
+    folder = tmp_path / "D0"
+    _write_csv(a, str(folder))
+    koff = np.concatenate(([0], np.cumsum(a.Jr)))
+    with open(folder / "process_data.csv", "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["kind", "task", "machine_selectable", "process_time", "power"])
+        for r in range(a.R):
+            for j in range(int(a.Jr[r])):
+                k = int(koff[r]) + j
+                ms = tuple(int(m) for m in a.elig_list[k, :a.elig_n[k]])
+                w.writerow([r, j, ms, tuple(int(a.p[k, m]) for m in ms), tuple(int(a.power[k, m]) for m in ms)])
+    off = np.concatenate(([0], np.cumsum(a.bk_n)))
+    with open(folder / "machine_data.csv", "w", newline="") as f:
+        w = csv.writer(f); w.writerow(["machine", "idle_power", "breakdown_start", "breakdown_end"])
+        for m in range(a.M):
+            if a.bk_n[m] == 0:
+                w.writerow([m, int(a.idle_power[m])])
+            for q in range(int(off[m]), int(off[m + 1])):
+                w.writerow([m, int(a.idle_power[m]) + (7 if q > off[m] else 0), int(a.bk[q, 0]), int(a.bk[q, 1])])   # later rows ignored
+    s = fi.InstanceSet(2).load_csv(0, str(tmp_path), "D0")
+    got = s.arrays(0)
+    assert np.array_equal(got.power, a.power) and np.array_equal(got.idle_power, a.idle_power)
+    assert np.array_equal(got.bk_n, a.bk_n) and np.array_equal(got.bk, a.bk)
+    assert np.array_equal(got.p, a.p) and got.ddt == float(int(a.ddt))
+    # ABI round trip on a raw instance
+    s.set_raw(1, a.Jr, a.p, a.elig_n, a.elig_list, a.count, a.arrive, a.delivery, a.ddt)
+    assert not hasattr(s.arrays(1), "power")
+    s.set_dynamic(1, a.power, a.idle_power, a.bk_n, a.bk)
+    rt = s.arrays(1)
+    assert np.array_equal(rt.power, a.power) and np.array_equal(rt.bk, a.bk) and np.array_equal(rt.idle_power, a.idle_power)
+    # create-time checks run before any device is touched
+    lib, h = _capi.lib(), C.c_void_p()
+    plain = H.instance_set_from(H.load_suite("mk01")[0])
+    assert lib.fjsp_env_create(plain.handle, 0, 1, 2, 4, 0, 0, C.byref(h)) == -7          # no machine data
+    assert b"machine data" in lib.fjsp_last_error()
+    s.set_x(1, a.x)
+    p2 = a.p.copy(); el_n = a.elig_n.copy(); el = a.elig_list.copy()
+    m_dead = a.M - 1                                   # strip the last machine from every operation that has another one
+    ok = True
+    for k in range(a.K):
+        if p2[k, m_dead] > 0:
+            if el_n[k] == 1:
+                ok = False
+                break
+            lst = [m for m in el[k, :el_n[k]] if m != m_dead]
+            p2[k, m_dead] = 0; el_n[k] = len(lst); el[k, :] = 0; el[k, :len(lst)] = lst
+    if ok:
+        bad = fi.InstanceSet(1).set_raw(0, a.Jr, p2, el_n, el, a.count, a.arrive, a.delivery, a.ddt)
+        bad.set_dynamic(0, np.where(p2 > 0, a.power, 0), a.idle_power, a.bk_n, a.bk).solve_fluid()
+        assert lib.fjsp_env_create(bad.handle, 0, 1, 2, 4, 0, 0, C.byref(h)) == -5         # Machine.gap_ave would divide by zero
+        assert b"no eligible operation" in lib.fjsp_last_error()
+
+
+def test_generated_machine_data_ranges(built):
+    """InstanceSet.generate_machine_data: the reference generator's power ranges (Instance_generate.py:61-66),
+    reproducible from the seed, windows sorted and disjoint per machine."""
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    s = fi.InstanceSet(2)
+    prm = fi.reference_generator_params(1.0, 12, 3)
+    for i in range(2):
+        s.generate(i, 99, prm).generate_machine_data(i, 5, max_windows=3)
+    a, b = s.arrays(0), s.arrays(1)
+    assert np.array_equal(a.power, b.power) and np.array_equal(a.bk, b.bk) and np.array_equal(a.idle_power, b.idle_power)
+    assert ((a.power > 0) == (a.p > 0)).all() and a.power[a.p > 0].min() >= 10 and a.power.max() <= 200
+    assert a.idle_power.min() >= 1 and a.idle_power.max() <= 9 and a.bk_n.max() <= 3 and len(a.bk) == a.bk_n.sum()
+    off = np.concatenate(([0], np.cumsum(a.bk_n)))
+    for m in range(a.M):
+        w = a.bk[off[m]:off[m + 1]]
+        assert (w[:, 0] < w[:, 1]).all() and (w[1:, 0] > w[:-1, 1]).all()
