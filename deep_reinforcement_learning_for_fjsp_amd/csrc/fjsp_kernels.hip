@@ -976,7 +976,7 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
     // lane 2 the machines' time_end (an exact integer sum, so the f64 walk equals sum(int)/M, :384-385);
     // the squared deviations are formed lane-parallel between the two walks so the second walk is a
     // pure add chain as well.  Rows are zero padded to a multiple of 8 (+0.0 is an exact identity).
-    const int n8 = (K + 7) & ~7;
+    const int n8 = (max(K, M) + 7) & ~7;      // (lane 2 walks M machine entries: a shop can have more machines than operation types)
     // (offset arithmetic, not a select between the pointer fields of `w`: that would pin `w` in scratch)
     const uint32_t src_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.frL) - fjsp_lds) +
                              (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));

@@ -447,6 +447,81 @@ def test_mo_dfjsp_full_size_batch_against_oracle_and_invariants(torch_gpu):
         assert fin["energy_consumption"][e] == want["energy"] and fin["completion_time"][e] == want["completion_time"], e
 
 
+@pytest.mark.parametrize("shape", ["small", "big"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
+    """Beyond the committed reference traces: freshly generated instances of mixed shape -- "small": 96 x (1-6
+    kinds, 1-4 stages, 1-12 machines, 1-4 jobs per kind), also shops with more machines than operation types;
+    "big": 24 x (8-24 kinds, 3-8 stages -> up to 192 operation types in one batch, i.e. the 2- and 4-chunk
+    kernels, 8-32 machines, 1-3 jobs per kind) -- 1-3 orders where the variant has arrivals, dense breakdown
+    windows for the dynamic variant, random actions over the variant's whole action space, HIP kernels vs the C
+    oracle (which is pinned to the reference on 2 921 episodes): choices, rewards, clocks and totals bit for bit,
+    states up to the pow() entries."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+    big = shape == "big"
+    N = 24 if big else 96
+    rs = np.random.RandomState(1000 + variant + (50 if big else 0))
+    s = fi.InstanceSet(N)
+    multi = variant in (0, 4)
+    for i in range(N):
+        if big:
+            R = int(rs.randint(8, 25)); Jlo = int(rs.randint(3, 8)); M = int(rs.randint(8, 33)); nmax = int(rs.randint(1, 4))
+        else:
+            R = int(rs.randint(1, 7)); Jlo = int(rs.randint(1, 4)); M = int(rs.randint(1, 13)); nmax = int(rs.randint(1, 5))
+        prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=1, p_max=int(rs.randint(2, 60)),
+                           N_min=1, N_max=nmax, S=int(rs.randint(1, 4)) if multi else 1,
+                           DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
+        seed = 50000 * (variant + 1) + i + (25000 if big else 0)
+        s.generate(i, seed, prm)
+        while variant == 4 and not (s.arrays(i).p > 0).any(axis=0).all():      # the reference divides by zero there
+            seed += 7919
+            s.generate(i, seed, prm)
+        if variant == 4:
+            s.generate_machine_data(i, seed, max_windows=4, window_gap=(1, 60), window_len=(1, 30))
+    s.solve_fluid()
+    arrs = [s.arrays(i) for i in range(N)]
+    T = max(int((a.count.sum(0) * a.Jr).sum()) for a in arrs)
+    n0, n1 = {0: (6, 5), 1: (20, 1), 2: (18, 1), 4: (12, 10)}[variant]
+    actions_h = np.stack([rs.randint(0, n0, (T, N)), rs.randint(0, n1, (T, N))], 2).astype(np.uint8)
+    actions = torch.from_numpy(actions_h).cuda()
+    b = EnvBatch(s, N, variant=variant, rng_seed=777 + variant)
+    mo_h = {0: None, 1: None, 2: (0.5, 0.5, 37.0, 91.0), 4: (3.0, 41.0, 17.0, 977.0)}[variant]
+    mo = None if mo_h is None else torch.tensor(mo_h, dtype=torch.float64).repeat(N, 1).cuda()
+    st0 = b.reset().cpu().numpy()
+    S = b.state_size
+    rewards = np.zeros((T, N)); states = np.zeros((T, N, S))
+    for t in range(T):
+        st, r, d = b.step(actions[t], mo=mo)
+        rewards[t] = r.cpu().numpy(); states[t] = st.cpu().numpy()
+    fin = {k: v.cpu().numpy() for k, v in b.read().items()}
+    assert (fin["done"] == 1).all() and (fin["status"] & ~4 == 0).all()
+    kw = {0: {}, 1: dict(sf=True), 2: dict(mo=True), 4: dict(dyn=True)}[variant]
+    for e, a in enumerate(arrs):
+        want = H.play_oracle(a, a.x, actions_h[:, e], b.env_seed(e), variant=variant, mo=mo_h)
+        Te = want["T"]
+        tag = "variant %d env %d (R=%d M=%d S=%d)" % (variant, e, a.R, a.M, a.S)
+        assert fin["step_count"][e] == Te, tag
+        assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(want["reward"])), tag + " reward"
+        H.assert_state_close(st0[e], want["state0"], tag + " reset", **kw)
+        H.assert_state_close(states[:Te, e], want["states"], tag, **kw)
+        assert fin["makespan"][e] == want["makespan"] and fin["delay_time_sum"][e] == want["delay_time_sum"], tag
+        assert fin["step_time"][e] == want["step_time"][-1], tag
+        if variant == 4:
+            assert fin["energy_consumption"][e] == want["energy"] and fin["completion_time"][e] == want["completion_time"], tag
+    # the fused T-step kernel (or its step-launch fallback) agrees with the per-step launches bit for bit
+    b2 = EnvBatch(s, N, variant=variant, rng_seed=777 + variant)
+    b2.reset()
+    tr, rw, st_last = b2.rollout(actions, mo=mo)
+    fin2 = {k: v.cpu().numpy() for k, v in b2.read().items()}
+    assert np.array_equal(H.bits(rw.cpu().numpy()), H.bits(rewards))
+    for key in ("delay_time_sum", "makespan", "step_time", "step_count", "completion_time"):
+        assert np.array_equal(fin[key], fin2[key]), key
+    Ks = fin["step_count"]
+    assert np.array_equal(H.bits(st_last.cpu().numpy()), H.bits(states[Ks - 1, np.arange(N)]))
+
+
 def test_instance_sharing_and_masked_reset(torch_gpu):
     """env e plays instance e % n_inst; reset(mask) restarts only the masked envs (the others keep going)."""
     torch = torch_gpu
