@@ -447,13 +447,13 @@ def test_mo_dfjsp_full_size_batch_against_oracle_and_invariants(torch_gpu):
         assert fin["energy_consumption"][e] == want["energy"] and fin["completion_time"][e] == want["completion_time"], e
 
 
-@pytest.mark.parametrize("shape", ["small", "big"])
+@pytest.mark.parametrize("shape", ["small", "big", "jobs"])
 @pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     """Beyond the committed reference traces: freshly generated instances of mixed shape -- "small": 96 x (1-6
     kinds, 1-4 stages, 1-12 machines, 1-4 jobs per kind), also shops with more machines than operation types;
     "big": 24 x (8-24 kinds, 3-8 stages -> up to 192 operation types in one batch, i.e. the 2- and 4-chunk
-    kernels, 8-32 machines, 1-3 jobs per kind) -- 1-3 orders where the variant has arrivals, dense breakdown
+    kernels, 8-32 machines, 1-3 jobs per kind); "jobs": 32 x (1-4 kinds with up to 60 jobs each) -- 1-3 orders where the variant has arrivals, dense breakdown
     windows for the dynamic variant, random actions over the variant's whole action space, HIP kernels vs the C
     oracle (which is pinned to the reference on 2 921 episodes): choices, rewards, clocks and totals bit for bit,
     states up to the pow() entries."""
@@ -461,19 +461,21 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     from deep_reinforcement_learning_for_fjsp_amd import instances as fi
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
     big = shape == "big"
-    N = 24 if big else 96
-    rs = np.random.RandomState(1000 + variant + (50 if big else 0))
+    N = {"small": 96, "big": 24, "jobs": 32}[shape]
+    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70}[shape])
     s = fi.InstanceSet(N)
     multi = variant in (0, 4)
     for i in range(N):
-        if big:
+        if shape == "jobs":      # few kinds, many jobs per kind (list positions, FIFO order, several job-table chunks)
+            R = int(rs.randint(1, 5)); Jlo = int(rs.randint(2, 5)); M = int(rs.randint(2, 9)); nmax = int(rs.randint(20, 61))
+        elif big:
             R = int(rs.randint(8, 25)); Jlo = int(rs.randint(3, 8)); M = int(rs.randint(8, 33)); nmax = int(rs.randint(1, 4))
         else:
             R = int(rs.randint(1, 7)); Jlo = int(rs.randint(1, 4)); M = int(rs.randint(1, 13)); nmax = int(rs.randint(1, 5))
         prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=1, p_max=int(rs.randint(2, 60)),
                            N_min=1, N_max=nmax, S=int(rs.randint(1, 4)) if multi else 1,
                            DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
-        seed = 50000 * (variant + 1) + i + (25000 if big else 0)
+        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000}[shape]
         s.generate(i, seed, prm)
         while variant == 4 and not (s.arrays(i).p > 0).any(axis=0).all():      # the reference divides by zero there
             seed += 7919
