@@ -166,6 +166,26 @@ def main():
                          "core (%d steps); reference Python itself: ~%.0f env-steps/s on one core (build container, "
                          "tests/golden/GENERATION_REPORT.txt)" % (n_s, dt, steps, REFERENCE_PYTHON_STEPS_PER_S)}
 
+    # the same port on the host cores the box gives one GPU (16): one oracle env per thread, ctypes releases the GIL
+    cpu_mt = None
+    if cpu is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = min(16, os.cpu_count() or 1)
+        shards = [envs[i::n_thr] for i in range(n_thr)]
+
+        def worker(my, deadline):
+            n_steps = 0
+            while time.perf_counter() < deadline:
+                for oe, act in my:
+                    n_steps += oe.play(act)[0]
+            return n_steps
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(n_thr) as ex:
+            done_steps = sum(ex.map(lambda my: worker(my, t0 + 5.0), shards))
+        dt = time.perf_counter() - t0
+        cpu_mt = {"value": done_steps / dt, "unit": "env-steps/s", "cores": n_thr, "kind": "port",
+                  "sample": "the same %d oracle environments spread over %d host threads for %.1f s" % (n_s, n_thr, dt)}
+
     if rank == 0:
         total_steps = N * world * args.steps
         # average launch duration = HIP events bracketing the K timed launches on the launch stream / K
@@ -202,6 +222,7 @@ def main():
                          "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": region_us,
                          "launch_us_per_launch_events": kern_us},
             "cpu_baseline": cpu,
+            "cpu_baseline_multicore": cpu_mt,
             "fused": fused,
         }
         print(json.dumps(out))
