@@ -109,7 +109,11 @@ class DDQN(Base_Agent, Config):
         self.global_step_number = 0
         self.completed_time = float("inf")
         self.best_state_dict = None
-        self.last_loss = None
+        self._last_loss = None
+
+    @property
+    def last_loss(self):
+        return None if self._last_loss is None else float(self._last_loss)
 
     # -- acting ---------------------------------------------------------------------------------
     @torch.no_grad()
@@ -124,6 +128,7 @@ class DDQN(Base_Agent, Config):
         state = env.reset().clone()
         done = torch.zeros(env.N, dtype=torch.uint8, device=self.device)
         limit = self.max_steps or 100000
+        played = torch.zeros((), dtype=torch.int64, device=self.device)
         t = 0
         while t < limit:
             active = done == 0
@@ -131,11 +136,12 @@ class DDQN(Base_Agent, Config):
             nxt, rew, dn = env.step(action)
             if learn_from:
                 self.memory.add_batch(state, action, rew, nxt, dn, active)
-                self.global_step_number += int(active.sum().item())
+                played += active.sum()
             state, done = nxt.clone(), dn.clone()
             t += 1
-            if bool((done != 0).all()):
+            if t % 16 == 0 and bool((done != 0).all()):          # one host round trip per 16 vector steps
                 break
+        self.global_step_number += int(played.item())
         return env.read()
 
     def step(self):
@@ -173,8 +179,8 @@ class DDQN(Base_Agent, Config):
         torch.nn.utils.clip_grad_norm_(self.q_network_local.parameters(), hp["gradient_clipping_norm"])
         self.q_network_optimizer.step()
         self.soft_update_of_target_network(self.q_network_local, self.q_network_target, hp["tau"])
-        self.last_loss = float(loss.detach())
-        return self.last_loss
+        self._last_loss = loss.detach()          # read lazily: no sync in the update loop
+        return self._last_loss
 
     def save_policy_network(self, path):
         torch.save(self.best_state_dict or self.q_network_local.state_dict(), path)

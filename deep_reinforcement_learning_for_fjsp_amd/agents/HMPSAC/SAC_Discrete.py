@@ -135,7 +135,11 @@ class SAC_Discrete(Base_Agent, Config):
         self.global_step_number = 0
         self._next_learn = hp["update_every_n_steps"]
         self.learn_sessions = 0
-        self.last_losses = None
+        self._last_losses = None
+
+    @property
+    def last_losses(self):
+        return None if self._last_losses is None else tuple(float(v) for v in self._last_losses)
 
     def load_policy_model(self, root):
         """:184-195; `root`/policy_networks_v5.{1,2,3}/actor_{task,machine}_model.path"""
@@ -187,6 +191,7 @@ class SAC_Discrete(Base_Agent, Config):
             env.set_objective(0)
         state = env.reset().clone()
         done = torch.zeros(env.N, dtype=torch.uint8, device=self.device)
+        played = torch.zeros((), dtype=torch.int64, device=self.device)     # transitions since the last host visit
         for t in range(self.max_steps):
             active = done == 0
             if which is None:
@@ -197,14 +202,20 @@ class SAC_Discrete(Base_Agent, Config):
             nxt, rew, dn = env.step(pair)
             if which is None:
                 self.memory.add_batch(state, action, rew, nxt, dn, active)
-                self.global_step_number += int(active.sum().item())
-                if self.time_for_critic_and_actor_to_learn():
-                    for _ in range(hp["learning_updates_per_learning_session"]):
-                        self.learn()
-                    self.learn_sessions += 1
+                played += active.sum()
             state, done = nxt.clone(), dn.clone()
-            if t % 16 == 15 and bool((done != 0).all()):         # (a host round trip: not every step)
-                break
+            if t % 16 == 15:                                     # one host round trip per 16 vector steps
+                if which is None:
+                    self.global_step_number += int(played.item())
+                    played.zero_()
+                    if self.time_for_critic_and_actor_to_learn():
+                        for _ in range(hp["learning_updates_per_learning_session"]):
+                            self.learn()
+                        self.learn_sessions += 1
+                if bool((done != 0).all()):
+                    break
+        if which is None:
+            self.global_step_number += int(played.item())
         r = env.read()
         return torch.stack([r["completion_time"].double(), r["delay_time_sum"].double(), r["energy_consumption"].double()], 1)
 
@@ -263,5 +274,5 @@ class SAC_Discrete(Base_Agent, Config):
                 self.log_alpha.grad /= fdist.world_size()
             self.alpha_optim.step()
             self.alpha = self.log_alpha.exp()
-        self.last_losses = (float(qf1_loss.detach()), float(qf2_loss.detach()), float(policy_loss.detach()))
-        return self.last_losses
+        self._last_losses = (qf1_loss.detach(), qf2_loss.detach(), policy_loss.detach())     # read lazily: no sync here
+        return self._last_losses

@@ -49,37 +49,36 @@ class DeviceReplayBuffer(object):
     def __init__(self, buffer_size, batch_size, state_size, device, seed=0):
         self.capacity, self.batch_size, self.device = int(buffer_size), int(batch_size), torch.device(device)
         f = dict(dtype=torch.float32, device=self.device)
-        self.states = torch.zeros(self.capacity, state_size, **f)
-        self.next_states = torch.zeros(self.capacity, state_size, **f)
-        self.actions = torch.zeros(self.capacity, 1, **f)
-        self.rewards = torch.zeros(self.capacity, 1, **f)
-        self.dones = torch.zeros(self.capacity, 1, **f)
-        self.size, self.head = 0, 0
+        # one scratch row past the ring takes the rows of finished environments (see add_batch)
+        self._rows = [torch.zeros(self.capacity + 1, w, **f) for w in (state_size, state_size, 1, 1, 1)]
+        self.states, self.next_states, self.actions, self.rewards, self.dones = (r[:self.capacity] for r in self._rows)
+        self._head = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._size = torch.zeros((), dtype=torch.int64, device=self.device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
 
     def add_batch(self, states, actions, rewards, next_states, dones, active=None):
-        """Append the rows with active != 0 (all rows when None). Tensors are [N, ...] on the device."""
-        if active is not None:
-            idx = torch.nonzero(active.reshape(-1) != 0).reshape(-1)
-            if idx.numel() == 0:
-                return 0
-            states, actions, rewards = states[idx], actions[idx], rewards[idx]
-            next_states, dones = next_states[idx], dones[idx]
-        n = states.shape[0]
-        if n > self.capacity:                          # keep the newest rows, like deque(maxlen)
-            states, actions, rewards = states[-self.capacity:], actions[-self.capacity:], rewards[-self.capacity:]
-            next_states, dones = next_states[-self.capacity:], dones[-self.capacity:]
-            n = self.capacity
-        pos = (self.head + torch.arange(n, device=self.device)) % self.capacity
-        self.states[pos] = states.float()
-        self.next_states[pos] = next_states.float()
-        self.actions[pos] = actions.float().reshape(n, 1)
-        self.rewards[pos] = rewards.float().reshape(n, 1)
-        self.dones[pos] = dones.float().reshape(n, 1)
-        self.head = (self.head + n) % self.capacity
-        self.size = min(self.capacity, self.size + n)
-        return n
+        """Append the rows with active != 0 (all rows when None).  Tensors are [N, ...] on the device.
+
+        No host round trip: the ring positions of the live rows come from a prefix sum of the mask, the dead rows
+        are routed to a scratch row past the ring, and head / size stay device scalars (`len()` reads them)."""
+        n_rows = states.shape[0]
+        if n_rows > self.capacity:
+            raise ValueError("a vector step larger than the replay ring (%d > %d)" % (n_rows, self.capacity))
+        if active is None:
+            live = torch.ones(n_rows, dtype=torch.bool, device=self.device)
+        else:
+            live = active.reshape(-1) != 0
+        rank = torch.cumsum(live.to(torch.int64), 0) - 1
+        n_live = rank[-1] + 1
+        pos = torch.where(live, (self._head + rank) % self.capacity, torch.full_like(rank, self.capacity))
+        self._rows[0][pos] = states.float()
+        self._rows[1][pos] = next_states.float()
+        self._rows[2][pos] = actions.float().reshape(n_rows, 1)
+        self._rows[3][pos] = rewards.float().reshape(n_rows, 1)
+        self._rows[4][pos] = dones.float().reshape(n_rows, 1)
+        self._head.copy_((self._head + n_live) % self.capacity)
+        self._size.copy_(torch.clamp(self._size + n_live, max=self.capacity))
 
     def add_experience(self, states, actions, rewards, next_states, dones):
         """Single-transition form of the reference's method (host values)."""
@@ -88,9 +87,14 @@ class DeviceReplayBuffer(object):
 
     def sample(self, num_experiences=None):
         k = self.batch_size if num_experiences is None else int(num_experiences)
-        assert k <= self.size, "not enough experiences (random.sample would raise ValueError)"
-        idx = torch.randperm(self.size, generator=self.gen, device=self.device)[:k]       # without replacement
+        size = len(self)
+        assert k <= size, "not enough experiences (random.sample would raise ValueError)"
+        idx = torch.randperm(size, generator=self.gen, device=self.device)[:k]            # without replacement
         return self.states[idx], self.actions[idx], self.rewards[idx], self.next_states[idx], self.dones[idx]
+
+    @property
+    def size(self):
+        return int(self._size.item())
 
     def __len__(self):
         return self.size

@@ -36,8 +36,10 @@ def test_device_replay_ring():
     mk = lambda lo, n: (torch.arange(lo, lo + n).double().unsqueeze(1).repeat(1, 3), torch.arange(lo, lo + n),
                         -torch.arange(lo, lo + n).double(), torch.arange(lo, lo + n).double().unsqueeze(1).repeat(1, 3) + 0.5,
                         torch.zeros(n, dtype=torch.uint8))
-    assert buf.add_batch(*mk(0, 5), active=torch.tensor([1, 1, 0, 1, 1])) == 4 and len(buf) == 4
-    assert buf.add_batch(*mk(10, 6)) == 6 and len(buf) == 8            # wraps: oldest two rows overwritten
+    buf.add_batch(*mk(0, 5), active=torch.tensor([1, 1, 0, 1, 1]))
+    assert len(buf) == 4
+    buf.add_batch(*mk(10, 6))
+    assert len(buf) == 8                                               # wraps: oldest two rows overwritten
     kept = sorted(buf.actions[:, 0].tolist())
     assert kept == [3.0, 4.0, 10.0, 11.0, 12.0, 13.0, 14.0, 15.0]
     s, a, r, n, d = buf.sample()
@@ -47,6 +49,8 @@ def test_device_replay_ring():
     assert len(buf) == 8 and 7.0 in buf.actions[:, 0].tolist()
     with pytest.raises(AssertionError):
         DeviceReplayBuffer(8, 4, 3, "cpu").sample()
+    with pytest.raises(ValueError):
+        buf.add_batch(*mk(0, 9))                                       # a vector step larger than the ring
 
 
 def test_ddqn_loss_is_double_q_learning():
