@@ -62,6 +62,7 @@ SIGNATURES = {
     "fjsp_rollout_clear": (C.c_int, [_vp]),
     "fjsp_rollout_len": (C.c_int, [_vp]),
     "fjsp_rollout_ptr": (_vp, [_vp, _i32]),
+    "fjsp_policy_sample": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -186,15 +186,59 @@ class PPOLearner(object):
             old_param.data.copy_(new_param.data)
 
 
-def _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, check_done):
+class FusedSampler(object):
+    """pick_action_and_log_prob (MPPPO.py:272-284) of a whole vector step in one launch of the library's
+    `fjsp_policy_sample` (csrc/fjsp_rollout_buffer.hip) instead of ~15 small torch kernels: Categorical sample,
+    epsilon override, log-probability, and the action already in the environment's u8 encoding.
+    pair_div = size of the machine-rule axis for pair-action environments ([6, 5] -> 5), 0 for flat actions."""
+
+    def __init__(self, N, T, n_actions, pair_div, device):
+        from ... import _capi
+        self._lib, self._check = _capi.lib(), _capi.check
+        self.N, self.A, self.div = int(N), int(n_actions), int(pair_div)
+        self.eps = torch.zeros((), dtype=torch.float32, device=device)
+        self.seed = torch.zeros((), dtype=torch.int64, device=device)
+        self.pair = torch.zeros(N, 2, dtype=torch.uint8, device=device)
+        self.flat_actions = torch.zeros(T, N, dtype=torch.float32, device=device)
+        self.rounds = 0
+
+    def new_round(self, exploration):
+        """Fresh random stream + exploration rate for the next rollout (device scalars: a captured graph reads them)."""
+        self.rounds += 1
+        self.eps.fill_(float(exploration))
+        self.seed.fill_((torch.initial_seed() * 0x9E3779B1 + self.rounds * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF)
+
+    def sample(self, probs, t, log_prob_row):
+        import ctypes as C
+        p = probs.contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+        ptr = lambda x: C.c_void_p(x.data_ptr())
+        self._check(self._lib.fjsp_policy_sample(ptr(p), self.N, self.A, self.div, ptr(self.eps), ptr(self.seed), int(t),
+                                                 ptr(self.pair), ptr(self.flat_actions[t]), ptr(log_prob_row), stream))
+        return self.pair
+
+
+def _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, check_done, fused=None):
     """T vector steps: policy inference, epsilon override, HIP env step, rollout-buffer append (MPPPO.py:245-252).
-    `exploration` is a float (eager) or a 0-dim device tensor (graph capture: no host branch on its value)."""
+    `exploration` is a float (eager) or a 0-dim device tensor (graph capture: no host branch on its value);
+    with a FusedSampler the sampling chain is one library launch and the exploration rate lives in the sampler."""
     memory.clear()
     state64 = env.reset().clone()
     done = torch.zeros(env.N, dtype=torch.uint8, device=env.device)
     t = 0
     while t < T:
         active = (done == 0).to(torch.uint8)
+        if fused is not None:
+            with torch.no_grad():
+                probs = learner.actor_new(state64.float())
+            act_pair = fused.sample(probs, t, old_log_prob[t])
+            nxt, rew, dn = env.batch.step(act_pair, mo=getattr(env, "mo", None))
+            memory.add_experience(state64, act_pair, rew, nxt, dn, active)
+            state64, done = nxt.clone(), dn.clone()
+            t += 1
+            if check_done and t % 8 == 0 and bool((done != 0).all()):
+                break
+            continue
         a, lp = learner.act(state64.float(), exploration)
         old_log_prob[t] = lp
         nxt, rew, dn = env.step(encode_action(a))
@@ -215,13 +259,14 @@ class GraphedRollout(object):
     so that it can change between replays; there is no early exit, every replay plays T steps (finished
     environments idle, their rows are masked by `valid`)."""
 
-    def __init__(self, env, learner, memory, T, encode_action):
-        self.env, self.learner, self.memory, self.T = env, learner, memory, T
+    def __init__(self, env, learner, memory, T, encode_action, fused=None):
+        self.env, self.learner, self.memory, self.T, self.fused = env, learner, memory, T, fused
         dev = env.device
         self.eps = torch.zeros((), device=dev)
         self.old_log_prob = torch.zeros(T, env.N, device=dev)
         self.pair = torch.zeros(env.N, 2, dtype=torch.uint8, device=dev)
-        body = lambda: _rollout_body(env, learner, memory, self.old_log_prob, self.eps, T, encode_action, self.pair, False)
+        body = lambda: _rollout_body(env, learner, memory, self.old_log_prob, self.eps, T, encode_action, self.pair, False,
+                                     fused)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):               # warm-up outside the capture (library handles, allocator)
@@ -234,11 +279,13 @@ class GraphedRollout(object):
 
     def run(self, exploration):
         self.eps.fill_(float(exploration))
+        if self.fused is not None:
+            self.fused.new_round(exploration)
         self.graph.replay()
         return self.memory, self.old_log_prob
 
 
-def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action, use_graph=False):
+def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action, use_graph=False, pair_div=None):
     """One batched episode on `env` with `learner`'s policy + one learning round (MPPPO.py:230-270).
 
     env.step(action_tensor) must accept what encode_action(flat_action) returns.  Returns
@@ -252,18 +299,30 @@ def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encod
         memory = RolloutBuffer(T, N, env.state_size, device=device.index or 0)
         memory_holder["memory"] = memory
         memory_holder.pop("graph", None)
+        memory_holder.pop("fused", None)
+    fused = None
+    if pair_div is not None and device.type == "cuda":       # one-launch sampling (library kernel)
+        fused = memory_holder.get("fused")
+        if fused is None or fused.N != N or fused.flat_actions.shape[0] < T or fused.A != learner.action_size or fused.div != pair_div:
+            fused = FusedSampler(N, T, learner.action_size, pair_div, device)
+            memory_holder["fused"] = fused
+            memory_holder.pop("graph", None)
     if use_graph:
         g = memory_holder.get("graph")
-        if g is None or g.env is not env or g.learner is not learner or g.memory is not memory or g.T != T:
-            g = GraphedRollout(env, learner, memory, T, encode_action)
+        if g is None or g.env is not env or g.learner is not learner or g.memory is not memory or g.T != T or g.fused is not fused:
+            g = GraphedRollout(env, learner, memory, T, encode_action, fused)
             memory_holder["graph"] = g
         _, old_log_prob = g.run(exploration)
     else:
         old_log_prob = torch.zeros(T, N, device=device)
         pair = torch.zeros(N, 2, dtype=torch.uint8, device=device)
-        _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, True)
+        if fused is not None:
+            fused.new_round(exploration)
+        _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, True, fused)
     n = len(memory)
     states, actions, _, _, _ = memory.sample()
+    if fused is not None:
+        actions = fused.flat_actions[:n].unsqueeze(-1)
     valid = memory.valid[:n]
     G = memory.compute_returns(hp["discount_rate"])
     G = normalise_returns(G, valid, hp["normalized_rewards"], hp["standardized_rewards"])
@@ -277,10 +336,12 @@ class PPO(Base_Agent):
     `environment` is a BatchedSOFJSSP; the flat action a in [0, 30) is the rule pair
     (a // 5, a % 5) of SO_FJSSP's [6, 5] action space."""
 
-    def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None, use_graph=False):
+    def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None, use_graph=False,
+                 fused_sampling=False):
         super().__init__()
         self.environment = environment
         self.use_graph = use_graph
+        self.fused_sampling = fused_sampling
         self.device = environment.device
         self.state_size = environment.state_size
         self.action_size = environment.actions_size[0] * environment.actions_size[1]
@@ -308,7 +369,8 @@ class PPO(Base_Agent):
         if exploration is None:                                                         # :240-241
             exploration = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])
         memory, losses = collect_and_learn(self.environment, self.learner, self._holder, exploration,
-                                           self.max_steps or 64, self._encode, use_graph=self.use_graph)
+                                           self.max_steps or 64, self._encode, use_graph=self.use_graph,
+                                           pair_div=self.environment.actions_size[1] if self.fused_sampling else None)
         self.global_step_number += int(memory.valid[:len(memory)].sum().item())
         self.episode_number += 1
         r = self.environment.read()

@@ -224,6 +224,16 @@ int fjsp_rollout_len(const fjsp_rollout *b);
  * 3 next_states f32[T][N][S], 4 dones f32[T][N], 5 valid f32[T][N], 6 returns f32[T][N]. */
 void *fjsp_rollout_ptr(fjsp_rollout *b, int32_t which);
 
+/* pick_action_and_log_prob (agents/MPPPO/MPPPO.py:272-284) for one vector step in ONE launch: samples
+ * Categorical(d_probs[env]) (f32[n][n_actions], the actor's softmax output), applies the epsilon-random
+ * override (*d_epsilon, device scalar so that captured graphs can change it), and writes the flat action
+ * (d_action f32[n]), its log-probability (d_log_prob f32[n]) and the action in the environment's encoding
+ * (d_pair u8[n][2] = (a / pair_div, a % pair_div), or (a, 0) when pair_div == 0).  Random numbers are a
+ * counter-based function of (*d_seed, counter, env). */
+int fjsp_policy_sample(const float *d_probs, int32_t n, int32_t n_actions, int32_t pair_div, const float *d_epsilon,
+                       const uint64_t *d_seed, uint64_t counter, uint8_t *d_pair, float *d_action, float *d_log_prob,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,8 +50,45 @@ def test_rollout_buffer_append_and_returns(torch_gpu):
         buf.add_experience(*rows[0])        # full
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu, use_graph):
+def test_policy_sample_kernel(torch_gpu):
+    """fjsp_policy_sample == pick_action_and_log_prob (MPPPO.py:272-284): the action frequencies follow the
+    probabilities, the log-probability is torch's Categorical.log_prob of the taken action, the pair encoding is
+    (a // div, a % div), epsilon = 1 gives uniform actions, and a new seed gives a new stream."""
+    torch = torch_gpu
+    from torch.distributions import Categorical
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import FusedSampler
+    N, A, T = 8192, 30, 4
+    torch.manual_seed(0)
+    probs = torch.softmax(torch.randn(1, A, device="cuda") * 1.5, -1).repeat(N, 1).contiguous()
+    fs = FusedSampler(N, T, A, 5, torch.device("cuda", 0))
+    logp = torch.zeros(T, N, device="cuda")
+    fs.new_round(0.0)
+    counts = torch.zeros(A, device="cuda")
+    for t in range(T):
+        pair = fs.sample(probs, t, logp[t]).clone()
+        a = fs.flat_actions[t].long()
+        assert torch.equal(pair[:, 0].long(), a // 5) and torch.equal(pair[:, 1].long(), a % 5)
+        want = Categorical(probs, validate_args=False).log_prob(a)
+        torch.testing.assert_close(logp[t], want, rtol=1e-5, atol=1e-6)
+        counts += torch.bincount(a, minlength=A).float()
+    freq = (counts / counts.sum()).cpu().numpy()
+    assert np.abs(freq - probs[0].cpu().numpy()).max() < 0.01                 # 32k samples
+    first = fs.flat_actions[0].clone()
+    assert not torch.equal(first, fs.flat_actions[1])                         # the step counter moves the stream
+    fs.new_round(0.0); fs.sample(probs, 0, logp[0])
+    assert not torch.equal(first, fs.flat_actions[0])                         # and so does the round seed
+    fs.new_round(1.0); fs.sample(probs, 0, logp[0])
+    uni = torch.bincount(fs.flat_actions[0].long(), minlength=A).float() / N
+    assert float((uni - 1.0 / A).abs().max()) < 0.01
+    flat = FusedSampler(N, T, 18, 0, torch.device("cuda", 0))
+    flat.new_round(0.0)
+    pr = torch.softmax(torch.randn(N, 18, device="cuda"), -1)
+    pair = flat.sample(pr, 0, logp[0])
+    assert torch.equal(pair[:, 0].long(), flat.flat_actions[0].long()) and int(pair[:, 1].sum()) == 0
+
+
+@pytest.mark.parametrize("use_graph,fused", [(False, False), (True, False), (False, True), (True, True)])
+def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu, use_graph, fused):
     """BASELINE config 3 in miniature: 256 envs, actor/critic 2x128, three learning rounds; eager rollout and the
     rollout replayed from a captured HIP graph (policy + env kernel + buffer append, MPPPO.GraphedRollout)."""
     torch = torch_gpu
@@ -62,7 +99,7 @@ def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu, use_graph):
     s = fi.InstanceSet(N).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
     env = BatchedSOFJSSP(s, rng_seed=3)
     torch.manual_seed(0)
-    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=use_graph)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=use_graph, fused_sampling=fused)
     K = np.array([s.dims(i)["K"] for i in range(N)])
     for rnd in range(3):
         tard, mk, (c_loss, a_loss) = agent.run_one_policy_network()
