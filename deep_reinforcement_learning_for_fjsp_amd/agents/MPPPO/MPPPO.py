@@ -47,6 +47,12 @@ class ActorNet(nn.Module):
     def forward(self, x):
         return F.softmax(run_layers(self.layers, x), dim=-1)
 
+    def log_prob(self, x, actions):
+        """log of the softmax probability of `actions` -- what Categorical(self(x)).log_prob(actions) returns
+        (MPPPO.py:327-328), computed as log_softmax + gather: two passes over the [samples, actions] matrix
+        instead of softmax, renormalisation, clamp, log and gather."""
+        return F.log_softmax(run_layers(self.layers, x), dim=-1).gather(1, actions.unsqueeze(1)).squeeze(1)
+
 
 class CriticNet(nn.Module):
     """MPPPO.py:51-67"""
@@ -169,7 +175,7 @@ class PPOLearner(object):
                 self.critic_bucket.all_reduce()
                 torch.nn.utils.clip_grad_norm_(self.critic.parameters(), hp["gradient_clipping_norm"])
                 self.critic_optimizer.step()
-            new_log_prob = Categorical(self.actor_new(states), validate_args=False).log_prob(actions)
+            new_log_prob = self.actor_new.log_prob(states, actions)
             terms = actor_loss_terms(new_log_prob, old_log_prob, advantages, hp["clip_epsilon"])
             a_loss = -(terms * m).sum() / count                                         # -torch.mean(...), :351
             self.actor_optimizer.zero_grad()
