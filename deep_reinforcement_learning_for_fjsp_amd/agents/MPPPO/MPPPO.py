@@ -398,9 +398,10 @@ class MPPPO(Base_Agent):
     generated_new_environment() (:149-154,160)."""
 
     def __init__(self, make_train_env, test_env, actor_number=5, hidden_size=200, hidden_layer=5, critic_layer=3,
-                 seed=0, hyper=None, max_steps=64, evolve_every=30):
+                 seed=0, hyper=None, max_steps=64, evolve_every=30, fused_sampling=True):
         super().__init__()
         self.make_train_env, self.test_env = make_train_env, test_env
+        self.fused_sampling = fused_sampling
         self.device = test_env.device
         self.actor_number = actor_number
         self.policy_tuple = tuple(range(actor_number))
@@ -421,7 +422,8 @@ class MPPPO(Base_Agent):
         hp = self.hyper_parameters
         eps = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])      # :240
         environment.set_objective(self.weight_vector_dict[policy_number], completion, tardiness)
-        collect_and_learn(environment, self.learners[policy_number], self._holder, eps, self.max_steps, lambda a: a)
+        collect_and_learn(environment, self.learners[policy_number], self._holder, eps, self.max_steps, lambda a: a,
+                          pair_div=0 if self.fused_sampling else None)
         r = environment.read()
         return r["delay_time_sum"].double(), r["completion_time"].double()
 
