@@ -16,9 +16,13 @@
  *     owned by the caller unless stated otherwise;
  *   - k = koff[r] + j is the r-major operation-type index (kind_task_tuple
  *     order, environments/SO_DFJSP_instance_read.py:25);
- *   - the device entry points are asynchronous on the given stream and never
- *     synchronise; per-env errors are reported in the status array
- *     (fjsp_env_status), not by aborting the batch.
+ *   - the device entry points are asynchronous on the given stream and do not
+ *     synchronise, with one exception: for batches with order arrivals
+ *     (instances with more than one order, FJSP_VARIANT_MO_DFJSP)
+ *     fjsp_env_step / fjsp_env_rollout synchronise once per step to solve
+ *     the fluid LPs of the environments an order reached (SO_FJSSP.py:218-231);
+ *     per-env errors are reported in the status array (fjsp_env_read), not
+ *     by aborting the batch.
  */
 #ifndef FJSP_AMD_H
 #define FJSP_AMD_H
@@ -135,8 +139,12 @@ typedef struct fjsp_env fjsp_env;
 
 /* FJSP.__init__ + SO_FJSSP_Environment.__init__ (class_FJSSP.py:151-171,
  * SO_FJSSP.py:14-48) for N envs: env e uses instance (first + e % n_inst).
- * Packs the padded struct-of-arrays, uploads it to `device`, and runs the
- * fluid-table kernel (update_fluid_parameter, class_FJSSP.py:282-306). */
+ * Packs the padded struct-of-arrays, uploads it to `device`, runs the
+ * fluid-table kernel (update_fluid_parameter, class_FJSSP.py:282-306) and one
+ * internal reset that caches every instance's reset observation; the envs are
+ * then left in the "done" state, so a step before fjsp_env_reset is flagged
+ * FJSP_ST_STEP_AFTER_DONE (or starts a fresh episode with autoreset).
+ * variant: FJSP_VARIANT_*; FJSP_VARIANT_MO_DFJSP needs instances with machine data. */
 int  fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int32_t n_envs,
                      int32_t variant, int32_t device, uint64_t rng_seed, fjsp_env **out);
 void fjsp_env_destroy(fjsp_env *e);
