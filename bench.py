@@ -171,20 +171,20 @@ def main():
     if cpu is not None:
         from concurrent.futures import ThreadPoolExecutor
         n_thr = min(16, os.cpu_count() or 1)
-        shards = [envs[i::n_thr] for i in range(n_thr)]
+        per = (len(envs) + n_thr - 1) // n_thr           # contiguous shards: neighbouring oracle envs share cache lines
+        shards = [envs[i * per:(i + 1) * per] for i in range(n_thr) if envs[i * per:(i + 1) * per]]
 
         def worker(my, deadline):
             n_steps = 0
             while time.perf_counter() < deadline:
-                for oe, act in my:
-                    n_steps += oe.play(act)[0]
+                n_steps += pyoracle.play_many(my, 8)      # 8 episodes of each env per C call, GIL released
             return n_steps
         t0 = time.perf_counter()
-        with ThreadPoolExecutor(n_thr) as ex:
+        with ThreadPoolExecutor(len(shards)) as ex:
             done_steps = sum(ex.map(lambda my: worker(my, t0 + 5.0), shards))
         dt = time.perf_counter() - t0
-        cpu_mt = {"value": done_steps / dt, "unit": "env-steps/s", "cores": n_thr, "kind": "port",
-                  "sample": "the same %d oracle environments spread over %d host threads for %.1f s" % (n_s, n_thr, dt)}
+        cpu_mt = {"value": done_steps / dt, "unit": "env-steps/s", "cores": len(shards), "kind": "port",
+                  "sample": "the same %d oracle environments spread over %d host threads (fjo_play_many, 8 episodes per C call) for %.1f s" % (n_s, n_thr, dt)}
 
     if rank == 0:
         total_steps = N * world * args.steps

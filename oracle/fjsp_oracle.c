@@ -146,6 +146,7 @@ struct fjo_env {
     ilist *ktm;
     /* LP hook / rng */
     fjo_lp_fn lp; void *lp_user;
+    double *fixed_x;            /* when set: the fluid solution of every LP (single-order instances: one LP per reset) */
     uint64_t rng_seed, rng_calls;
     /* jobs (job_dict, arrival order) */
     job_t *jobs; int njobs, jobs_cap;
@@ -266,11 +267,17 @@ void fjo_destroy(fjo_env *e) {
     free(e->time_sum); free(e->fl_n); free(e->fl_list); free(e->mstate); free(e->tend); free(e->mjob);
     free(e->rate); free(e->arr); free(e->un); free(e->fu); free(e->x); free(e->delay_time_a);
     free(e->delay_time_e); free(e->urgency); free(e->due_min); free(e->jobs);
+    free(e->fixed_x);
     free(e->power); free(e->idle_power); free(e->bk_n); free(e->bk_off); free(e->bk); free(e->tlast); free(e->ntask);
     free(e);
 }
 
 void fjo_set_lp(fjo_env *e, fjo_lp_fn fn, void *user) { e->lp = fn; e->lp_user = user; }
+void fjo_set_fixed_x(fjo_env *e, const double *x) {
+    free(e->fixed_x);
+    e->fixed_x = (double *)malloc(sizeof(double) * (size_t)e->K * e->M);
+    memcpy(e->fixed_x, x, sizeof(double) * (size_t)e->K * e->M);
+}
 void fjo_set_dynamic(fjo_env *e, const int *power, const int *idle_power, const int *bk_n, const int *bk) {
     int K = e->K, M = e->M, tot = 0;
     e->power = (int *)malloc(sizeof(int) * (size_t)K * M); memcpy(e->power, power, sizeof(int) * (size_t)K * M);
@@ -356,7 +363,8 @@ static int reset_object_add(fjo_env *e, int s) {
         e->Qf[k] = (double)e->Q0[k];
     }
     if (!e->lp) return -10;
-    if (e->lp(e->lp_user, e->Q0, e->fluid_number, e->x) != 0) return -11;         /* :239 fluid_model */
+    if (e->fixed_x) memcpy(e->x, e->fixed_x, sizeof(double) * (size_t)e->K * e->M);  /* x supplied once (static instance) */
+    else if (e->lp(e->lp_user, e->Q0, e->fluid_number, e->x) != 0) return -11;    /* :239 fluid_model */
     /* :276-278 fluid_completed_time = max Q / rate_sum, rate_sum summed over machine_rj_dict order */
     {
         double best = 0.0; int first = 1;
@@ -908,6 +916,19 @@ int fjo_play(fjo_env *e, const unsigned char *actions, int max_T, double *reward
     }
     if (reward_sum) *reward_sum = acc;
     return t;
+}
+
+/* timing helper: `reps` full episodes of each of n environments in one call (the caller's thread keeps
+ * running without going back to the interpreter between episodes); returns the number of steps played */
+long fjo_play_many(fjo_env **envs, int n, const unsigned char *const *actions, int max_T, int reps) {
+    long steps = 0;
+    for (int q = 0; q < reps; ++q)
+        for (int i = 0; i < n; ++i) {
+            int t = fjo_play(envs[i], actions[i], max_T, NULL);
+            if (t < 0) return t;
+            steps += t;
+        }
+    return steps;
 }
 
 int     fjo_step_time(const fjo_env *e) { return e->step_time; }

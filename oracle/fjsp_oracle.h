@@ -70,6 +70,9 @@ int fjo_step(fjo_env *e, int a0, int a1, double *state, double *reward, int *don
  * completion/tardiness <= 0 stand for None. */
 int fjo_step_mo(fjo_env *e, int action, double w0, double w1, double completion, double tardiness,
                 double *state, double *reward, int *done, fjo_trace *tr);
+/* A fixed fluid solution x[K*M] used for every LP instead of the hook (single-order instances: the one LP of
+ * reset); keeps the interpreter out of timing loops. */
+void fjo_set_fixed_x(fjo_env *e, const double *x);
 /* MO_DFJSP(_breakdown).py: machine data of the dynamic multi-objective env (power[K*M] k-major, idle_power[M],
  * bk_n[M] breakdown windows per machine, bk[] flattened (start, end) pairs machine-major; all zero windows
  * = MO_DFJSP.py).  Must be called before fjo_reset for variant FJO_MO_DFJSP. */
@@ -86,6 +89,7 @@ void fjo_set_ddt(fjo_env *e, double ddt);
 /* reset + step through actions[t][2] until done or max_T, entirely in C (cpu_baseline
  * timing without interpreter overhead).  Returns the number of steps, <0 on error. */
 int fjo_play(fjo_env *e, const unsigned char *actions, int max_T, double *reward_sum);
+long fjo_play_many(fjo_env **envs, int n, const unsigned char *const *actions, int max_T, int reps);
 
 /* read-back of attributes agents/harnesses read. */
 int     fjo_step_time(const fjo_env *e);

@@ -57,6 +57,9 @@ def lib():
                                    C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(Trace)]
         L.fjo_energy.argtypes = [C.c_void_p]
         L.fjo_energy.restype = C.c_int64
+        L.fjo_set_fixed_x.argtypes = [C.c_void_p, C.c_void_p]
+        L.fjo_play_many.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.fjo_play_many.restype = C.c_long
         L.fjo_step_sf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                   C.POINTER(Trace)]
         for name in ("fjo_step_time", "fjo_step_count", "fjo_makespan", "fjo_completion_time"):
@@ -119,6 +122,9 @@ class OracleEnv(object):
                 return 1
         self._hook = LP_FN(_hook)
         self.L.fjo_set_lp(self.h, self._hook, None)
+        if not callable(lp) and a.S == 1:          # static instance: no interpreter call per reset
+            self._keep.append(fixed)
+            self.L.fjo_set_fixed_x(self.h, fixed.ctypes.data)
         self.L.fjo_set_rng(self.h, rng_seed & (2 ** 64 - 1))
         if ddt is not None:
             self.L.fjo_set_ddt(self.h, float(ddt))
@@ -239,3 +245,17 @@ class OracleEnv(object):
         rs = np.zeros(self.K); ts = np.zeros(self.K)
         self.L.fjo_fluid_tables(self.h, rate.ctypes.data, arr.ctypes.data, rs.ctypes.data, ts.ctypes.data)
         return rate, arr, rs, ts
+
+
+def play_many(envs_and_actions, reps):
+    """Timing helper: `reps` full episodes of every (OracleEnv, actions u8[T, 2]) pair in ONE C call (the GIL is
+    released for its whole duration, so host threads scale).  Returns the number of steps played."""
+    n = len(envs_and_actions)
+    acts = [np.ascontiguousarray(a, dtype=np.uint8) for _, a in envs_and_actions]
+    T = min(len(a) for a in acts)
+    hs = (C.c_void_p * n)(*[e.h for e, _ in envs_and_actions])
+    ps = (C.c_void_p * n)(*[a.ctypes.data for a in acts])
+    steps = lib().fjo_play_many(hs, n, ps, T, int(reps))
+    if steps < 0:
+        raise RuntimeError("oracle play_many failed rc=%d" % steps)
+    return steps
