@@ -127,8 +127,11 @@ class PPOLearner(object):
         torch.random.set_rng_state(gen_state)
         Base_Agent.copy_model_over_dict(self.actor_new, self.actor_old)
         fused = self.device.type == "cuda"       # one multi-tensor kernel per optimiser step instead of one per parameter
-        self.actor_optimizer = optim.Adam(self.actor_new.parameters(), lr=self.hp["learning_rate"], eps=1e-4, fused=fused)
-        self.critic_optimizer = optim.Adam(self.critic.parameters(), lr=self.hp["learning_rate"], eps=1e-4, fused=fused)
+        adam = dict(lr=self.hp["learning_rate"], eps=1e-4, fused=fused, capturable=fused)   # capturable: step count on the device
+        self.actor_optimizer = optim.Adam(self.actor_new.parameters(), **adam)
+        self.critic_optimizer = optim.Adam(self.critic.parameters(), **adam)
+        self.graph_learn = False         # replay the learning round from a HIP graph once its sample count repeats
+        self._learn_graph = None
         self.action_size = action_size
         self.train_critic = train_critic
         self.actor_bucket = fdist.FlatGradBucket(self.actor_new.parameters())
@@ -162,7 +165,18 @@ class PPOLearner(object):
             states, actions, old_log_prob, returns = states[idx], actions[idx], old_log_prob[idx], returns[idx]
             vmask = torch.ones(idx.shape[0], dtype=torch.bool, device=states.device)
         m = vmask.to(states.dtype)
+        if self.graph_learn and states.is_cuda and not fdist.is_distributed():
+            return self._learn_graphed(states, actions, old_log_prob, returns, m)
         count = fdist.all_reduce_scalar_sum(m.sum())          # global number of samples
+        c_loss, a_loss = self._learn_body(states, actions, old_log_prob, returns, m, count)
+        return float(c_loss), float(a_loss)
+
+    def _learn_body(self, states, actions, old_log_prob, returns, m, count):
+        """The 10 critic + 10 actor iterations of critic_actor_learn (:314-323); returns the last (critic, actor) losses
+        as tensors."""
+        hp = self.hp
+        if count is None:
+            count = m.sum()                # single process: the sample count as a device scalar (no host round trip)
         with torch.no_grad():
             advantages = returns - self.critic(states).squeeze(1)                       # :263
         c_loss = a_loss = None
@@ -184,7 +198,30 @@ class PPOLearner(object):
             torch.nn.utils.clip_grad_norm_(self.actor_new.parameters(), hp["gradient_clipping_norm"])
             self.actor_optimizer.step()
         self.equalise_policies()
-        return float(c_loss.detach()), float(a_loss.detach())
+        return c_loss.detach(), a_loss.detach()
+
+    def _learn_graphed(self, states, actions, old_log_prob, returns, m):
+        """A learning round is ~1 200 small launches whose host cost rivals their device time.  With a fixed set
+        of environments the number of valid samples (one per operation) is the same every round, so the whole
+        round is captured once for that sample count and replayed: the first round of a given size runs eagerly
+        (it also creates the optimiser state the capture needs), the second is captured, later ones replay."""
+        n = states.shape[0]
+        g = self._learn_graph
+        if g is None or g["n"] != n:
+            self._learn_graph = {"n": n, "graph": None}
+            c, a = self._learn_body(states, actions, old_log_prob, returns, m, None)
+            return float(c), float(a)
+        if g["graph"] is None:
+            g["in"] = [t.clone() for t in (states, actions, old_log_prob, returns, m)]
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                g["out"] = self._learn_body(*g["in"], None)
+            g["graph"] = graph
+        for dst, src in zip(g["in"], (states, actions, old_log_prob, returns, m)):
+            dst.copy_(src)
+        g["graph"].replay()
+        return float(g["out"][0]), float(g["out"][1])
 
     def equalise_policies(self):
         """:372-375 with the AttributeError fixed."""
@@ -348,11 +385,13 @@ class PPO(Base_Agent):
         self.environment = environment
         self.use_graph = use_graph
         self.fused_sampling = fused_sampling
+        self.learner_graph = use_graph
         self.device = environment.device
         self.state_size = environment.state_size
         self.action_size = environment.actions_size[0] * environment.actions_size[1]
         self.learner = PPOLearner(self.state_size, self.action_size, hidden_size, hidden_layer, hidden_layer,
                                   device=self.device, seed=seed, hyper=hyper)
+        self.learner.graph_learn = bool(use_graph)
         self.hyper_parameters = self.learner.hp
         self.max_steps = max_steps
         self._holder = {}
