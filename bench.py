@@ -140,7 +140,14 @@ def main():
             torch.cuda.synchronize()
             tot += e0.elapsed_time(e1)
         steps_per_rollout = int(K.sum())
+        tot2 = 0.0
+        for _ in range(reps):                 # rule-sweep form: no state handed back, the kernel skips the observation
+            env2.reset()
+            e0.record(); env2.rollout(actions[:T], trace=False, rewards=False, state=False); e1.record()
+            torch.cuda.synchronize()
+            tot2 += e0.elapsed_time(e1)
         fused = {"kernel": "rollout_kernel", "env_steps_per_launch": steps_per_rollout,
+                 "env_steps_per_s_no_state": steps_per_rollout / (tot2 / reps * 1e-3),
                  "ms_per_launch": tot / reps, "env_steps_per_s": steps_per_rollout / (tot / reps * 1e-3),
                  "achieved_GBps": env.step_bytes * steps_per_rollout / (tot / reps * 1e-3) / 1e9}
 

@@ -94,16 +94,17 @@ class EnvBatch(object):
                                       _ptr(reward_out), _ptr(done_out), self._stream()))
         return state_out, reward_out, done_out
 
-    def rollout(self, actions, trace=True, rewards=True, mo=None):
-        """T fused steps in one launch. actions: uint8[T, N, 2]. Returns (trace_km i16[T,N,2], reward f64[T,N], state)."""
+    def rollout(self, actions, trace=True, rewards=True, mo=None, state=True):
+        """T fused steps in one launch. actions: uint8[T, N, 2]. Returns (trace_km i16[T,N,2], reward f64[T,N], state).
+        state=False: no final state (the fused kernel then skips the observation; reset before stepping again)."""
         if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
         T = actions.shape[0]
         tr = torch.full((T, self.N, 2), -1, dtype=torch.int16, device=self.device) if trace else None
         rw = torch.zeros(T, self.N, dtype=torch.float64, device=self.device) if rewards else None
-        check(self._lib.fjsp_env_rollout(self._h, _ptr(actions), _ptr(mo), int(T), _ptr(tr), _ptr(rw), _ptr(self.state),
-                                         self._stream()))
-        return tr, rw, self.state
+        check(self._lib.fjsp_env_rollout(self._h, _ptr(actions), _ptr(mo), int(T), _ptr(tr), _ptr(rw),
+                                         _ptr(self.state) if state else None, self._stream()))
+        return tr, rw, (self.state if state else None)
 
     # -- read back -----------------------------------------------------------------
     def read(self):

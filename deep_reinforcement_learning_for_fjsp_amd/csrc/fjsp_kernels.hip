@@ -929,7 +929,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
 // the chains cost one LDS read + one add per element instead of cross-lane traffic,
 // and two chains advance per instruction.
 template <int KC, int V>
-__device__ __forceinline__ long long observe(W<KC, V> &w) {
+__device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = false) {
     const int K = w.K, M = w.M;
     bool single_job = true;      // every operation type has exactly one job (10x5, Mk01..10): counts are 0 or 1
 #pragma unroll
@@ -972,6 +972,9 @@ __device__ __forceinline__ long long observe(W<KC, V> &w) {
         job_e = (int)(r3 & 0xFFFFu);
         tard_unproc = (long long)r4 + ((long long)(r3 >> 16) << 24);
     }
+    // a rollout that never hands a state back (rule sweeps read makespan / tardiness / energy only) needs the
+    // tardiness of the unfinished jobs for the reward and nothing else of the observation
+    if (stats_only) return V == FJSP_VARIANT_SO_SFJSP ? 0 : tard_unproc;
     // ---- the three mean / population-std pairs (:84-95).  Lane 0 walks finish_rate, lane 1 gap_rate,
     // lane 2 the machines' time_end (an exact integer sum, so the f64 walk equals sum(int)/M, :384-385);
     // the squared deviations are formed lane-parallel between the two walks so the second walk is a
@@ -1153,11 +1156,11 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
 // One environment step.  compute_params() must be current on entry and is
 // current again on exit (the fused kernel carries it across steps).
 template <int KC, int V>
-__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out);
+__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs = true);
 
 template <int KC, int V>
 __device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a0, int a1, const double *mo,
-                                           double *state_out, int *k_out, int *m_out) {
+                                           double *state_out, int *k_out, int *m_out, bool need_obs = true) {
     const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
         if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }   // IndexError
@@ -1187,12 +1190,12 @@ __device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a
     return 0.0;                                                                   // diagnostic: stop after dispatch_and_advance
 #endif
     if (is_mord_v<V> && w.pending) return 0.0;        // an order arrived: the step is finished by arrival_kernel
-    return env_step_finish<KC, V>(w, mo, state_out);
+    return env_step_finish<KC, V>(w, mo, state_out, need_obs);
 }
 
 // Second half of step() (SO_FJSSP.py:252-265): observation, reward, bookkeeping.
 template <int KC, int V>
-__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out) {
+__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs) {
     const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
     w.step_count++;                                                          // :252
     compute_params<KC, V>(w);
@@ -1202,9 +1205,9 @@ __device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo,
 #elif defined(FJSP_ABLATE) && FJSP_ABLATE == 1
     const long long tard_unproc = observe<KC, V>(w);   // diagnostic: observation computed, not emitted
 #else
-    const long long tard_unproc = observe<KC, V>(w);                           // :256
+    const long long tard_unproc = observe<KC, V>(w, !need_obs);                // :256
     STAMP(w, 6);
-    emit_state<KC, V>(w, state_out, false);
+    if (need_obs) emit_state<KC, V>(w, state_out, false);
     STAMP(w, 7);
 #endif
     const long long delay_new = w.tard_done + tard_unproc;                   // :259
@@ -1382,7 +1385,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t 
         const bool live = !w.done && !(w.status & (FJSP_ST_BAD_TASK_RULE | FJSP_ST_BAD_MACHINE_RULE | FJSP_ST_NO_EVENT));
         if (live) {
             const int a0 = actions[o * 2], a1 = actions[o * 2 + 1];
-            reward = env_step<KC, V>(w, &b, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel);
+            reward = env_step<KC, V>(w, &b, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_last, &k_sel, &m_sel,
+                                     state_last != nullptr);
         }
         if (w.lane == 0) {
             if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }

@@ -176,7 +176,10 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
  * d_actions u8[T][N][2]; d_mo as in fjsp_env_step (constant over the T steps);
  * envs that finish early idle (no autoreset).
  * Trace outputs (nullable): d_trace_km i16[T][N][2] = chosen (k, m) or -1,
- * d_reward f64[T][N], d_state_last f64[N][S]. */
+ * d_reward f64[T][N], d_state_last f64[N][S].  With d_state_last == NULL the
+ * fused kernel skips the observation altogether (rule sweeps read makespan /
+ * tardiness / energy only); the envs must then be reset before the next call
+ * that returns a state (the remembered v(t-1) is stale). */
 int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t T, int16_t *d_trace_km,
                      double *d_reward, double *d_state_last, void *stream);
 

@@ -522,6 +522,14 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
         assert np.array_equal(fin[key], fin2[key]), key
     Ks = fin["step_count"]
     assert np.array_equal(H.bits(st_last.cpu().numpy()), H.bits(states[Ks - 1, np.arange(N)]))
+    # ... and so does the stateless form (no observation inside the kernel): same choices, rewards and totals
+    b3 = EnvBatch(s, N, variant=variant, rng_seed=777 + variant)
+    b3.reset()
+    tr3, rw3, none = b3.rollout(actions, mo=mo, state=False)
+    fin3 = {k: v.cpu().numpy() for k, v in b3.read().items()}
+    assert none is None and torch.equal(tr3, tr) and np.array_equal(H.bits(rw3.cpu().numpy()), H.bits(rewards))
+    for key in ("delay_time_sum", "makespan", "step_time", "step_count", "completion_time"):
+        assert np.array_equal(fin[key], fin3[key]), key
 
 
 def test_instance_sharing_and_masked_reset(torch_gpu):
