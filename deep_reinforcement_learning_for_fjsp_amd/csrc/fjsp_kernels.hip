@@ -14,12 +14,18 @@
 //     before the first wait, so a step costs two dependent memory round trips
 //     (state in, column gather at the chosen operation) instead of a chain;
 //   * next-event selection is a DPP min-reduction over the machine lanes,
-//     availability sets are 64-bit ballots, rule argmax/argmin walk the ballot
-//     in index order with readlane so the reference's "first extremum wins"
-//     tie-break (CPython max/min) is kept, and every float sum that feeds a
-//     decision or the observation is accumulated serially in the reference's
-//     order (tree reductions would break bit-exactness).  Integer statistics
-//     use DPP row reductions.
+//     availability sets are 64-bit ballots, a task rule's argmax/argmin is a
+//     wave reduction of the key followed by the FIRST set bit of
+//     ballot(member && key == extremum), a machine rule's walks its few
+//     candidates in the list's (CPython set) order with readlane -- either way
+//     the reference's "first extremum wins" tie-break (CPython max/min) is
+//     kept -- and every float sum that feeds a decision or the observation is
+//     accumulated serially in the reference's order (tree reductions would
+//     break bit-exactness): the operands go to LDS rows and one lane per row
+//     walks them.  Integer statistics use ballots / DPP row reductions.
+//
+// Variants (template parameter V): SO_FJSSP, SO_SFJSP, MO_FJSSP_discretes, an internal multi-order
+// SO_FJSSP (order arrivals re-solve the fluid LP), and MO_DFJSP(_breakdown) on top of the latter.
 //
 // Reference restated (paths relative to the reference root):
 //   environments/SO_FJSSP.py:51-76    reset            -> init_episode + observe
@@ -27,7 +33,9 @@
 //   environments/SO_FJSSP.py:168-265  step             -> decide / dispatch / advance_clock / observe
 //   environments/SO_FJSSP.py:267-322  task_select, machine_select
 //   environments/SO_FJSSP.py:78-97    state_extract    -> observe
-//   environments/class_FJSSP.py:282-306 update_fluid_parameter -> fluid_tables_kernel
+//   environments/class_FJSSP.py:282-306 update_fluid_parameter -> fluid_tables_kernel, arrival_kernel
+//   environments/SO_FJSSP.py:218-231    order arrival    -> order_arrive + host LP service (fjsp_env.hip) + arrival_kernel
+//   environments/MO_DFJSP_breakdown.py:189-447 breakdown windows, energy, 12 x 10 rules, 15 observations, 4 rewards
 // Compiled with -ffp-contract=off: a*b+c must round twice like CPython.
 #include <hip/hip_runtime.h>
 
