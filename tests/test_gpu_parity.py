@@ -7,6 +7,8 @@ makespan and machine completion times BIT-EXACT; state vectors bit-exact except
 the three math.pow()-derived entries (tests/helpers.py POW_COLS), which are held
 to 1e-12 (the north star allows 1e-5).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -462,7 +464,8 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
     big = shape == "big"
     N = {"small": 96, "big": 24, "jobs": 32}[shape]
-    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70}[shape])
+    fuzz = int(os.environ.get("FJSP_FUZZ_SEED", "0"))          # tools/fuzz_parity.sh sweeps this
+    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70}[shape] + 1000 * fuzz)
     s = fi.InstanceSet(N)
     multi = variant in (0, 4)
     for i in range(N):
@@ -475,7 +478,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
         prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=1, p_max=int(rs.randint(2, 60)),
                            N_min=1, N_max=nmax, S=int(rs.randint(1, 4)) if multi else 1,
                            DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
-        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000}[shape]
+        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000}[shape] + 1000003 * fuzz
         s.generate(i, seed, prm)
         while variant == 4 and not (s.arrays(i).p > 0).any(axis=0).all():      # the reference divides by zero there
             seed += 7919
