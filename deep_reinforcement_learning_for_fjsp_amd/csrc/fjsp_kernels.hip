@@ -1128,6 +1128,11 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
             const int k = c * kWave + w.lane;
             const int r = (int)((w.kB[c] >> 16) & 0xFFu);
             w.q0[c] = ((w.kB[c] >> 24) & 2u) ? (int)reinterpret_cast<const uint16_t *>(w.ir + L.i_ocnt)[r] : 0;
+            // (a restart inside step_kernel arrives here with the PREVIOUS episode's last-arrival tables in the
+            // wave state: always take the reset-time ones from the instance record)
+            w.fmask[c] = reinterpret_cast<const uint32_t *>(w.ir + L.i_fmask)[k];
+            w.rate_sum[c] = reinterpret_cast<const double *>(w.ir + L.i_rsum)[k];
+            w.time_sum[c] = reinterpret_cast<const double *>(w.ir + L.i_tsum)[k];
             reinterpret_cast<uint32_t *>(w.er + L.e_fmask)[k] = w.fmask[c];
             reinterpret_cast<double *>(w.er + L.e_rsum)[k] = w.rate_sum[c];
             reinterpret_cast<double *>(w.er + L.e_tsum)[k] = w.time_sum[c];

@@ -533,6 +533,19 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     assert none is None and torch.equal(tr3, tr) and np.array_equal(H.bits(rw3.cpu().numpy()), H.bits(rewards))
     for key in ("delay_time_sum", "makespan", "step_time", "step_count", "completion_time"):
         assert np.array_equal(fin[key], fin3[key]), key
+    # autoreset: every env of `b` is done; a step with autoreset starts a fresh episode inside the launch (reset
+    # observation taken from the per-instance cache) and must equal reset() + step() on a fresh batch.  A
+    # deterministic rule pair is used (the random.choice stream continues across resets).
+    det = torch.tensor({0: (2, 0), 1: (0, 0), 2: (0, 0), 4: (2, 0)}[variant], dtype=torch.uint8).repeat(N, 1).cuda()
+    fresh = EnvBatch(s, N, variant=variant, rng_seed=5)
+    fresh.reset()
+    st_f, r_f, d_f = fresh.step(det, mo=mo)
+    st_a, r_a, d_a = b.step(det, autoreset=True, mo=mo)
+    assert torch.equal(st_a, st_f) and torch.equal(r_a, r_f) and torch.equal(d_a, d_f)
+    fa, ff = b.read(), fresh.read()
+    for key in ("step_time", "step_count", "delay_time_sum", "completion_time", "makespan"):
+        assert torch.equal(fa[key], ff[key]), key
+    assert int((fa["status"] != 0).sum()) == 0                 # the restart also cleared the sticky status bits
 
 
 def test_instance_sharing_and_masked_reset(torch_gpu):
