@@ -463,12 +463,14 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     from deep_reinforcement_learning_for_fjsp_amd import instances as fi
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
     big = shape == "big"
-    N = {"small": 96, "big": 24, "jobs": 32}[shape]
+    NI = {"small": 96, "big": 24, "jobs": 32}[shape]           # instances; they sit at an offset inside the set
+    OFF = 2
+    N = NI + NI // 4                                           # environments: the last quarter shares instances
     fuzz = int(os.environ.get("FJSP_FUZZ_SEED", "0"))          # tools/fuzz_parity.sh sweeps this
     rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70}[shape] + 1000 * fuzz)
-    s = fi.InstanceSet(N)
+    s = fi.InstanceSet(OFF + NI)
     multi = variant in (0, 4)
-    for i in range(N):
+    for i in range(OFF, OFF + NI):
         if shape == "jobs":      # few kinds, many jobs per kind (list positions, FIFO order, several job-table chunks)
             R = int(rs.randint(1, 5)); Jlo = int(rs.randint(2, 5)); M = int(rs.randint(2, 9)); nmax = int(rs.randint(20, 61))
         elif big:
@@ -485,13 +487,14 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
             s.generate(i, seed, prm)
         if variant == 4:
             s.generate_machine_data(i, seed, max_windows=4, window_gap=(1, 60), window_len=(1, 30))
-    s.solve_fluid()
-    arrs = [s.arrays(i) for i in range(N)]
+    s.solve_fluid(OFF, NI)
+    inst_arrs = [s.arrays(OFF + i) for i in range(NI)]
+    arrs = [inst_arrs[e % NI] for e in range(N)]              # env e plays instance first + e % n_inst
     T = max(int((a.count.sum(0) * a.Jr).sum()) for a in arrs)
     n0, n1 = {0: (6, 5), 1: (20, 1), 2: (18, 1), 4: (12, 10)}[variant]
     actions_h = np.stack([rs.randint(0, n0, (T, N)), rs.randint(0, n1, (T, N))], 2).astype(np.uint8)
     actions = torch.from_numpy(actions_h).cuda()
-    b = EnvBatch(s, N, variant=variant, rng_seed=777 + variant)
+    b = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=777 + variant)
     mo_h = {0: None, 1: None, 2: (0.5, 0.5, 37.0, 91.0), 4: (3.0, 41.0, 17.0, 977.0)}[variant]
     mo = None if mo_h is None else torch.tensor(mo_h, dtype=torch.float64).repeat(N, 1).cuda()
     st0 = b.reset().cpu().numpy()
@@ -516,7 +519,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
         if variant == 4:
             assert fin["energy_consumption"][e] == want["energy"] and fin["completion_time"][e] == want["completion_time"], tag
     # the fused T-step kernel (or its step-launch fallback) agrees with the per-step launches bit for bit
-    b2 = EnvBatch(s, N, variant=variant, rng_seed=777 + variant)
+    b2 = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=777 + variant)
     b2.reset()
     tr, rw, st_last = b2.rollout(actions, mo=mo)
     fin2 = {k: v.cpu().numpy() for k, v in b2.read().items()}
@@ -526,7 +529,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     Ks = fin["step_count"]
     assert np.array_equal(H.bits(st_last.cpu().numpy()), H.bits(states[Ks - 1, np.arange(N)]))
     # ... and so does the stateless form (no observation inside the kernel): same choices, rewards and totals
-    b3 = EnvBatch(s, N, variant=variant, rng_seed=777 + variant)
+    b3 = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=777 + variant)
     b3.reset()
     tr3, rw3, none = b3.rollout(actions, mo=mo, state=False)
     fin3 = {k: v.cpu().numpy() for k, v in b3.read().items()}
@@ -537,7 +540,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     # observation taken from the per-instance cache) and must equal reset() + step() on a fresh batch.  A
     # deterministic rule pair is used (the random.choice stream continues across resets).
     det = torch.tensor({0: (2, 0), 1: (0, 0), 2: (0, 0), 4: (2, 0)}[variant], dtype=torch.uint8).repeat(N, 1).cuda()
-    fresh = EnvBatch(s, N, variant=variant, rng_seed=5)
+    fresh = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=5)
     fresh.reset()
     st_f, r_f, d_f = fresh.step(det, mo=mo)
     st_a, r_a, d_a = b.step(det, autoreset=True, mo=mo)
@@ -546,6 +549,16 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     for key in ("step_time", "step_count", "delay_time_sum", "completion_time", "makespan"):
         assert torch.equal(fa[key], ff[key]), key
     assert int((fa["status"] != 0).sum()) == 0                 # the restart also cleared the sticky status bits
+    # masked reset one step into the episode: masked envs are back at their reset state and replay their first
+    # step, the others are untouched
+    mask_h = np.arange(N) % 3 == 0
+    mask = torch.from_numpy(mask_h.astype(np.uint8)).cuda()
+    first_step = st_f.clone()
+    st_m = fresh.reset(mask).clone()
+    assert np.array_equal(H.bits(st_m.cpu().numpy()[mask_h]), H.bits(st0[mask_h]))
+    assert torch.equal(st_m[~mask.bool()], first_step[~mask.bool()])
+    st_2, r_2, _ = fresh.step(det, mo=mo)
+    assert torch.equal(st_2[mask.bool()], first_step[mask.bool()]) and torch.equal(r_2[mask.bool()], r_f[mask.bool()])
 
 
 def test_instance_sharing_and_masked_reset(torch_gpu):
