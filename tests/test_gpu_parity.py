@@ -495,8 +495,19 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     actions_h = np.stack([rs.randint(0, n0, (T, N)), rs.randint(0, n1, (T, N))], 2).astype(np.uint8)
     actions = torch.from_numpy(actions_h).cuda()
     b = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=777 + variant)
-    mo_h = {0: None, 1: None, 2: (0.5, 0.5, 37.0, 91.0), 4: (3.0, 41.0, 17.0, 977.0)}[variant]
-    mo = None if mo_h is None else torch.tensor(mo_h, dtype=torch.float64).repeat(N, 1).cuda()
+    # step()'s extra arguments differ per environment: weight vectors with or without normalisers for the MO
+    # variant (MO_FJSSP_discretes.py:232-244), reward policies 0..3 for the dynamic one (MO_DFJSP_breakdown.py:430-447)
+    if variant == 2:
+        kinds = rs.randint(0, 3, N)
+        w0 = np.round(rs.rand(N), 2)
+        mo_rows = [(1.0, 0.0, -1.0, -1.0) if k == 0 else (0.0, 1.0, -1.0, -1.0) if k == 1 else
+                   (float(w0[e]), float(1.0 - w0[e]), float(rs.randint(20, 90)), float(rs.randint(30, 400))) for e, k in enumerate(kinds)]
+    elif variant == 4:
+        mo_rows = [(float(rs.randint(0, 4)), float(rs.randint(20, 90)), float(rs.choice([0.0, 17.0, 250.0])), float(rs.randint(500, 5000)))
+                   for _ in range(N)]
+    else:
+        mo_rows = None
+    mo = None if mo_rows is None else torch.tensor(mo_rows, dtype=torch.float64).cuda()
     st0 = b.reset().cpu().numpy()
     S = b.state_size
     rewards = np.zeros((T, N)); states = np.zeros((T, N, S))
@@ -507,7 +518,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     assert (fin["done"] == 1).all() and (fin["status"] & ~4 == 0).all()
     kw = {0: {}, 1: dict(sf=True), 2: dict(mo=True), 4: dict(dyn=True)}[variant]
     for e, a in enumerate(arrs):
-        want = H.play_oracle(a, a.x, actions_h[:, e], b.env_seed(e), variant=variant, mo=mo_h)
+        want = H.play_oracle(a, a.x, actions_h[:, e], b.env_seed(e), variant=variant, mo=None if mo_rows is None else mo_rows[e])
         Te = want["T"]
         tag = "variant %d env %d (R=%d M=%d S=%d)" % (variant, e, a.R, a.M, a.S)
         assert fin["step_count"][e] == Te, tag
