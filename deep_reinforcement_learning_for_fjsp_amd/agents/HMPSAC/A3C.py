@@ -120,20 +120,22 @@ class DA3C(Base_Agent, Config):
     OBJECTIVE_KEY = {0: "completion_time", 1: "delay_time_sum", 2: "energy_consumption"}
 
     def __init__(self, make_train_env, test_env, reward_policy=0, hidden_size=200, hidden_layer=3, hyper=None,
-                 seed=0, max_steps=4096):
+                 seed=0, max_steps=4096, state_size=30, actions_size=(12, 10)):
         Base_Agent.__init__(self)
         Config.__init__(self)
         self.hp = dict(self.hyper_parameters["DA3C"])
         self.hp.update(hyper or {})
         self.make_train_env, self.environment_test = make_train_env, test_env
         self.device = test_env.device
-        self.reward_policy = int(reward_policy)
-        self.actions_size = [12, 10]
+        # reward_policy None: an environment without reward policies (agents/DA3C/DA3C_double_actor.py trains the same
+        # networks at sizes 20 -> 6 / 21 -> 5 on SO_DFJSP, objective = total tardiness)
+        self.reward_policy = None if reward_policy is None else int(reward_policy)
+        self.state_size, self.actions_size = int(state_size), [int(actions_size[0]), int(actions_size[1])]
         rng = torch.random.get_rng_state()
         torch.manual_seed(seed)
-        self.actor_task_model = TaskPolicyNet(30, hidden_size, hidden_layer, 12).to(self.device)
-        self.actor_machine_model = MachinePolicyNet(31, hidden_size, hidden_layer, 10).to(self.device)
-        self.critic_model = CriticNet(30, hidden_size, hidden_layer, 1).to(self.device)
+        self.actor_task_model = TaskPolicyNet(self.state_size, hidden_size, hidden_layer, self.actions_size[0]).to(self.device)
+        self.actor_machine_model = MachinePolicyNet(self.state_size + 1, hidden_size, hidden_layer, self.actions_size[1]).to(self.device)
+        self.critic_model = CriticNet(self.state_size, hidden_size, hidden_layer, 1).to(self.device)
         torch.random.set_rng_state(rng)
         lr = self.hp["learning_rate"]
         self.nets = (self.actor_task_model, self.actor_machine_model, self.critic_model)
@@ -152,12 +154,12 @@ class DA3C(Base_Agent, Config):
         s = state.float()
         a_t = Categorical(self.actor_task_model(s), validate_args=False).sample()
         if eps is not None:
-            rnd = torch.randint(0, 12, a_t.shape, device=s.device)
+            rnd = torch.randint(0, self.actions_size[0], a_t.shape, device=s.device)
             a_t = torch.where(torch.rand(a_t.shape, device=s.device) <= eps, rnd, a_t)
         s2 = torch.cat([s, a_t.float().unsqueeze(1)], 1)
         a_m = Categorical(self.actor_machine_model(s2), validate_args=False).sample()
         if eps is not None:
-            rnd = torch.randint(0, 10, a_m.shape, device=s.device)
+            rnd = torch.randint(0, self.actions_size[1], a_m.shape, device=s.device)
             a_m = torch.where(torch.rand(a_m.shape, device=s.device) <= eps, rnd, a_m)
         return a_t, a_m
 
@@ -169,7 +171,8 @@ class DA3C(Base_Agent, Config):
         return (eps / d + u * (eps * d - eps / d)).clamp(min=0.0)
 
     def _rollout(self, env, eps):
-        env.set_objective(self.reward_policy)
+        if self.reward_policy is not None:
+            env.set_objective(self.reward_policy)
         state = env.reset().clone()
         N = env.N
         done = torch.zeros(N, dtype=torch.uint8, device=self.device)
@@ -220,7 +223,8 @@ class DA3C(Base_Agent, Config):
     @torch.no_grad()
     def run_test(self):
         env = self.environment_test
-        env.set_objective(self.reward_policy)
+        if self.reward_policy is not None:
+            env.set_objective(self.reward_policy)
         state = env.reset().clone()
         pair = torch.zeros(env.N, 2, dtype=torch.uint8, device=self.device)
         for t in range(self.max_steps):
@@ -230,7 +234,8 @@ class DA3C(Base_Agent, Config):
             state = state.clone()
             if t % 16 == 15 and bool((done != 0).all()):
                 break
-        return float(env.read()[self.OBJECTIVE_KEY[self.reward_policy]].double().mean())
+        key = self.OBJECTIVE_KEY[1 if self.reward_policy is None else self.reward_policy]
+        return float(env.read()[key].double().mean())
 
     def save_actor_model(self, folder):
         """:241-246 file names, so SAC_Discrete.load_policy_model finds them."""

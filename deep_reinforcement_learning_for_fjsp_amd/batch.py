@@ -17,6 +17,7 @@ VARIANT_SO_FJSSP = 0
 VARIANT_SO_SFJSP = 1
 VARIANT_MO_FJSSP_DISCRETES = 2
 VARIANT_MO_DFJSP = 4
+VARIANT_SO_DFJSP = 5
 
 ST_BAD_TASK_RULE = 1
 ST_BAD_MACHINE_RULE = 2

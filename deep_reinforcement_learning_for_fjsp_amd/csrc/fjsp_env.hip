@@ -144,6 +144,9 @@ extern "C" {
 
 int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int32_t n_envs, int32_t variant,
                     int32_t device, uint64_t rng_seed, fjsp_env **out) {
+    // SO_DFJSP.py = SO_FJSSP.py over class_FJSP.py: the same kernels, the order's delivery time as every job's due date
+    const bool class_fjsp = variant == FJSP_VARIANT_SO_DFJSP;
+    if (class_fjsp) variant = FJSP_VARIANT_SO_FJSSP;
     if (!s || !out || first < 0 || n_inst <= 0 || n_envs <= 0 || (size_t)first + (size_t)n_inst > s->v.size()) {
         set_error("fjsp_env_create: bad arguments"); return FJSP_E_ARG;
     }
@@ -156,6 +159,14 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         const Instance &in = s->v[(size_t)first + i];
         if (!in.valid) { set_error("fjsp_env_create: instance not populated"); return FJSP_E_STATE; }
         if (!in.has_x) { set_error("fjsp_env_create: fluid solution missing (call fjsp_instances_solve_fluid)"); return FJSP_E_STATE; }
+        if (class_fjsp) {
+            for (int m = 0; m < in.M; ++m) {
+                bool any = false;
+                for (int k = 0; k < in.K; ++k) any = any || in.p[(size_t)k * in.M + m] > 0;
+                // class_FJSP.py:159 divides by len(kind_task_tuple); with at least one operation type n + 1e-18 == n in f64
+                if (!any) { set_error("SO_DFJSP: a machine with no eligible operation (ZeroDivisionError in the reference)"); return FJSP_E_UNSUPPORTED; }
+            }
+        }
         if (dyn) {
             if (!in.has_dynamic) { set_error("MO_DFJSP needs machine data (machine_data.csv / fjsp_instances_set_dynamic)"); return FJSP_E_STATE; }
             int nb = 0;
@@ -273,7 +284,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
                 const int c_s = in.count[(size_t)so * in.R + r];
                 const long r_due = py_round((double)((long)in.delivery[so] * in.Jr[r]) / (double)c_s);
                 for (int n = cnt; n < cnt + c_s; ++n) {
-                    due[jbeg + n] = dyn ? in.delivery[so]                                 // class_MODFJSP.py:224
+                    due[jbeg + n] = (dyn || class_fjsp) ? in.delivery[so]                 // class_MODFJSP.py:224, class_FJSP.py:229
                                         : (int32_t)py_round((double)(r_due * n) / (double)c_s);
                     jinfo[jbeg + n] = (uint32_t)in.koff[r] | ((uint32_t)in.Jr[r] << 16);
                 }

@@ -38,11 +38,12 @@ class BatchedSOFJSSP(object):
     actions_size = [6, 5]
     action_types = "DISCRETE"
     state_size = 20
+    variant = VARIANT_SO_FJSSP          # (environments/SO_DFJSP.py subclasses with its own variant)
 
     def __init__(self, instance_set, n_envs=None, first=0, n_inst=None, device=0, rng_seed=0):
         n_inst = len(instance_set) - first if n_inst is None else n_inst
         n_envs = n_inst if n_envs is None else n_envs
-        self.batch = EnvBatch(instance_set, n_envs, first=first, n_inst=n_inst, variant=VARIANT_SO_FJSSP,
+        self.batch = EnvBatch(instance_set, n_envs, first=first, n_inst=n_inst, variant=self.variant,
                               device=device, rng_seed=rng_seed)
         self.N = self.batch.N
         self.device = self.batch.device
@@ -81,6 +82,7 @@ class SO_FJSSP_Environment(object):
     (SO_DFJSP_instance_read.py:7).  The fluid LP (class_FJSSP.py:246-280) is solved by the
     library at construction; its solution is an input of the kernels.
     """
+    variant = VARIANT_SO_FJSSP
 
     def __init__(self, use_instance=True, device=0, **kwargs):
         self._device = device
@@ -107,7 +109,7 @@ class SO_FJSSP_Environment(object):
         self.order_tuple = tuple(range(a.S))
         self.kind_task_tuple = a.kind_task_tuple
         self._rng_seed = random.getrandbits(63) if rng_seed is None else rng_seed
-        self._batch = EnvBatch(self._set, 1, variant=VARIANT_SO_FJSSP, device=self._device, rng_seed=self._rng_seed)
+        self._batch = EnvBatch(self._set, 1, variant=self.variant, device=self._device, rng_seed=self._rng_seed)
         # SO_FJSSP.py:17-33
         self.step_count = 0
         self.step_time = 0

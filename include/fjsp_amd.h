@@ -58,6 +58,9 @@ enum {
     FJSP_VARIANT_SO_FJSSP = 0,          /* environments/SO_FJSSP.py (pair action [6,5], 20-dim state) */
     FJSP_VARIANT_SO_SFJSP = 1,          /* environments/SO_SFJSP.py (flat 20 = 4x5, 18-dim state, makespan)  */
     FJSP_VARIANT_MO_FJSSP_DISCRETES = 2,/* environments/MO_FJSSP_discretes.py (flat 18, 25-dim state)  */
+    FJSP_VARIANT_SO_DFJSP = 5,          /* environments/SO_DFJSP.py (agents/DA3C's environment): SO_FJSSP.py over
+                                           class_FJSP.py -- job due date = the order's delivery time (class_FJSP.py:229),
+                                           Machine.gap_ave without the 1e-18 (:159); same actions, state and kernels */
     FJSP_VARIANT_MO_DFJSP = 4           /* environments/MO_DFJSP_breakdown.py (and MO_DFJSP.py = no breakdown windows):
                                            pair action [12,10], 30-dim state, order arrivals, machine breakdowns,
                                            energy; needs instances with machine data (fjsp_instances_set_dynamic

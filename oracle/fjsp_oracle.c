@@ -146,6 +146,7 @@ struct fjo_env {
     ilist *ktm;
     /* LP hook / rng */
     fjo_lp_fn lp; void *lp_user;
+    int class_fjsp;             /* SO_DFJSP.py: SO_FJSSP semantics over class_FJSP.py */
     double *fixed_x;            /* when set: the fluid solution of every LP (single-order instances: one LP per reset) */
     uint64_t rng_seed, rng_calls;
     /* jobs (job_dict, arrival order) */
@@ -201,8 +202,13 @@ static int rng_choice(fjo_env *e, int n) {
 static long py_round(double v) { return (long)nearbyint(v); }
 
 fjo_env *fjo_create(const fjo_instance *in, int variant) {
+    /* environments/SO_DFJSP.py is SO_FJSSP.py over class_FJSP.py instead of class_FJSSP.py: job due date = the
+     * order's delivery time (class_FJSP.py:229) and Machine.gap_ave without the 1e-18 (:159) */
+    const int class_fjsp = variant == FJO_SO_DFJSP;
+    if (class_fjsp) variant = FJO_SO_FJSSP;
     if (variant != FJO_SO_FJSSP && variant != FJO_SO_SFJSP && variant != FJO_MO_FJSSP_DISCRETES && variant != FJO_MO_DFJSP) return NULL;
     fjo_env *e = (fjo_env *)calloc(1, sizeof(*e));
+    e->class_fjsp = class_fjsp;
     e->variant = variant;
     e->R = in->R; e->M = in->M; e->K = in->K; e->S = in->S;
     int R = e->R, M = e->M, K = e->K, S = e->S;
@@ -349,7 +355,7 @@ static int reset_object_add(fjo_env *e, int s) {
             int id = e->njobs++;
             job_t *jb = &e->jobs[id];
             jb->kind = r; jb->n = n; jb->next_j = 0; jb->time_arrive = e->arrive[s];
-            jb->due = (e->variant == FJO_MO_DFJSP) ? e->delivery[s]                 /* class_MODFJSP.py:224 */
+            jb->due = (e->variant == FJO_MO_DFJSP || e->class_fjsp) ? e->delivery[s] /* class_MODFJSP.py:224, class_FJSP.py:229 */
                                                    : (int)py_round((double)(r_due * n) / (double)cnt);           /* :218 */
             e->kind_arrived[r]++;
             il_push(&e->kind_unproc[r], id);
@@ -420,7 +426,7 @@ static double machine_gap_rj(const fjo_env *e, int m, int k) { return e->un[k * 
 static double machine_gap_ave(const fjo_env *e, int m) {
     double s = 0.0;
     for (int i = 0; i < e->ktm[m].n; ++i) s = s + machine_gap_rj(e, m, e->ktm[m].v[i]);
-    if (e->variant == FJO_MO_DFJSP) return s / (double)e->ktm[m].n;             /* class_MODFJSP.py:158-159 */
+    if (e->variant == FJO_MO_DFJSP || e->class_fjsp) return s / (double)e->ktm[m].n;   /* class_MODFJSP.py:158-159, class_FJSP.py:159 */
     return s / ((double)e->ktm[m].n + 1e-18);
 }
 

@@ -51,7 +51,7 @@ typedef struct {
 } fjo_trace;
 
 /* Variants share one skeleton. */
-enum { FJO_SO_FJSSP = 0, FJO_SO_SFJSP = 1, FJO_MO_FJSSP_DISCRETES = 2, FJO_MO_DFJSP = 4 };
+enum { FJO_SO_FJSSP = 0, FJO_SO_SFJSP = 1, FJO_MO_FJSSP_DISCRETES = 2, FJO_MO_DFJSP = 4, FJO_SO_DFJSP = 5 };
 
 fjo_env *fjo_create(const fjo_instance *inst, int variant);
 void     fjo_destroy(fjo_env *e);

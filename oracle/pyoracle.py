@@ -16,6 +16,7 @@ SO_FJSSP = 0
 SO_SFJSP = 1
 MO_FJSSP_DISCRETES = 2
 MO_DFJSP = 4
+SO_DFJSP = 5
 
 
 class _Inst(C.Structure):

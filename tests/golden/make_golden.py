@@ -122,7 +122,7 @@ def check_loader_against_reference(arr, env):
         assert tuple(env.count_sr_dict[s]) == tuple(int(c) for c in arr.count[s])
         assert env.time_arrive_s_dict[s] == int(arr.arrive[s])
         assert env.time_delivery_s_dict[s] == int(arr.delivery[s])
-    if hasattr(env, "power_m_dict"):
+    if hasattr(env, "breakdown_m_dict"):
         off = np.concatenate(([0], np.cumsum(arr.bk_n)))
         for m in range(arr.M):
             assert env.power_m_dict[m] == int(arr.idle_power[m])
@@ -228,7 +228,7 @@ def run_reference(EnvCls, arr, folder_parent, folder_name, actions, rng_seed, ch
         while not env.done:
             a = actions[t]
             t0 = time.perf_counter()
-            if mo is None:
+            if mo is None or mo == "sod":
                 s, r, d = env.step([int(a[0]), int(a[1])])
             elif mo == "sf":
                 s, r, d = env.step(int(a[0]))
@@ -264,6 +264,8 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
     lp = lambda Q, now: fi.fluid_lp(arr.Jr, arr.p, Q, now)[0]
     if mo is None:
         env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_FJSSP, rng_seed)
+    elif mo == "sod":
+        env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_DFJSP, rng_seed)
     elif mo == "sf":
         env = pyoracle.OracleEnv(arr, lp, pyoracle.SO_SFJSP, rng_seed)
     elif mo[0] == "dyn":
@@ -275,7 +277,7 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
     state0 = env.reset()
     t = 0
     while not env.done:
-        if mo is None:
+        if mo is None or mo == "sod":
             s, r, d = env.step(actions[t])
         elif mo == "sf":
             s, r, d = env.step_sf(int(actions[t][0]))
@@ -296,7 +298,7 @@ def run_oracle(arr, actions, rng_seed, T, mo=None):
     out["delay_time_sum"] = env.delay_time_sum
     out["fluid_completed_time"] = env.fluid_completed_time
     out["completion_time"] = env.completion_time
-    out["energy"] = env.energy_consumption if mo is not None and mo != "sf" and mo[0] == "dyn" else 0
+    out["energy"] = env.energy_consumption if mo is not None and mo not in ("sf", "sod") and mo[0] == "dyn" else 0
     out["T"] = t
     return out
 
@@ -343,9 +345,9 @@ def store_episode(store, prefix, inst_idx, kind, rng_seed, actions, ref, full_st
     store[prefix + "state_last"] = ref["states"][-1]
     store[prefix + "completion"] = np.int64(ref.get("completion_time", 0))
     store[prefix + "energy"] = np.int64(ref.get("energy", 0))
-    if mo is not None and mo != "sf" and mo[0] == "dyn":   # [reward_policy, completion, tardiness, energy] (-1 = None)
+    if mo is not None and mo not in ("sf", "sod") and mo[0] == "dyn":   # [reward_policy, completion, tardiness, energy] (-1 = None)
         store[prefix + "mo"] = np.array([mo[1]] + [-1.0 if v is None else v for v in mo[2:5]], np.float64)
-    elif mo is not None and mo != "sf":
+    elif mo is not None and mo not in ("sf", "sod"):
         store[prefix + "mo"] = np.array([mo[0], mo[1], -1.0 if mo[2] is None else mo[2], -1.0 if mo[3] is None else mo[3]], np.float64)
     if full_states:
         store[prefix + "states"] = ref["states"]
@@ -370,6 +372,7 @@ def main():
     from environments.MO_FJSSP_discretes import MO_FJSSP_Environment
     from environments.SO_SFJSP import SO_SFJSP_Environment
     from environments.MO_DFJSP_breakdown import MO_DFJSP_Environment
+    from environments.SO_DFJSP import SO_DFJSP_Environment
 
     tmp = tempfile.mkdtemp(prefix="fjsp_golden_")
     report = []
@@ -380,7 +383,7 @@ def main():
         if args.only and args.only != name:
             return
         EnvCls = {"so": SO_FJSSP_Environment, "mo": MO_FJSSP_Environment, "sf": SO_SFJSP_Environment,
-                  "dyn": MO_DFJSP_Environment}[variant]
+                  "dyn": MO_DFJSP_Environment, "sod": SO_DFJSP_Environment}[variant]
         store = {}
         suite_base = splitmix64(sum(ord(ch) for ch in name) * 7919)
         store["rng_seed_base"] = np.uint64(suite_base)
@@ -393,8 +396,8 @@ def main():
             checked_loader = False
             mo_memo = {}
             for plan in plans_store(ci) + [tuple(pl) + (False,) for pl in plans_verify(ci)]:
-                if variant in ("so", "sf"):
-                    (kind, seed, keep), mo = plan, (None if variant == "so" else "sf")
+                if variant in ("so", "sf", "sod"):
+                    (kind, seed, keep), mo = plan, {"so": None, "sf": "sf", "sod": "sod"}[variant]
                 elif variant == "dyn":
                     # (kind, seed, reward_policy, keep); policy 3 takes its normalisers from the policy 0/1/2 runs
                     kind, seed, policy, keep = plan
@@ -406,7 +409,7 @@ def main():
                     cn = mo_memo.get("completion") if mo_spec[2] else None
                     tn = mo_memo.get("tardiness") if mo_spec[2] else None
                     mo = (mo_spec[0], mo_spec[1], cn, tn)
-                actions = action_stream(kind, seed, Tmax, {"so": None, "mo": 18, "sf": 20, "dyn": "dyn"}[variant])
+                actions = action_stream(kind, seed, Tmax, {"so": None, "mo": 18, "sf": 20, "dyn": "dyn", "sod": None}[variant])
                 # stored episode e of a suite plays with random.choice stream seed
                 # suite_base + e * 1000003 == the seed env e of a batch created with
                 # rng_seed = suite_base gets (fjsp_kernels.hip bind()); verify-only
@@ -414,10 +417,10 @@ def main():
                 rng_seed = (suite_base + ep_id * 1000003) & MASK64 if keep else splitmix64(seed * 1000003 + ci)
                 ref, env = run_reference(EnvCls, arr, parent, folder, actions, rng_seed,
                                          check_lp=(n_eps % 16 == 0), timing=timing, mo=mo)
-                if variant == "dyn" and mo[1] != 3:
+                if variant == "dyn" and mo[1] != 3:   # noqa: E129
                     mo_memo[("completion", "tardiness", "energy")[mo[1]]] = (ref["completion_time"], ref["delay_time_sum"],
                                                                               ref["energy"])[mo[1]]
-                if variant == "mo" and mo != "sf":      # MPPPO.py:161-164: the single-objective runs supply the normalisers
+                if variant == "mo":      # MPPPO.py:161-164: the single-objective runs supply the normalisers
                     if mo[0] == 1 and mo[2] is None:
                         mo_memo["completion"] = ref["completion_time"]
                     if mo[1] == 1 and mo[2] is None:
@@ -614,6 +617,34 @@ def main():
                       (DYN_PAIRS[(ci * 53 + 67) % 120], 0, 2, True)],
           lambda ci: ([] if args.quick else [(kp, 0, 3) for kp in (DYN_PAIRS if ci >= len(dyn_cases) else DYN_PAIRS[ci::7])]),
           full_state_eps={0, 3}, variant="dyn")
+
+    # ---- suite 8: SO_DFJSP (agents/DA3C's environment): SO_FJSSP over class_FJSP.py (due date = order delivery) ------
+    sod_cases = [("benchmark/Brandimarte_Data", "Mk01"), ("DDQN", "P11"), ("HMPSAC", "DDT0.5_M10_S1"), ("HMPSAC", "DDT1.0_M15_S3")]
+    if args.quick:
+        sod_cases = sod_cases[:2]
+    s8 = fi.InstanceSet(len(sod_cases) + 3)
+    for i, (d, f) in enumerate(sod_cases):
+        s8.load_csv(i, REF + "/data/" + d, f)
+    sod_prm = [dict(R_min=3, R_max=3, J_min=2, J_max=3, M=4, p_min=20, p_max=90, N_min=2, N_max=4, S=3, DDT=1.0),
+               dict(R_min=4, R_max=4, J_min=3, J_max=4, M=9, p_min=5, p_max=60, N_min=1, N_max=3, S=2, DDT=0.5),
+               dict(R_min=2, R_max=2, J_min=1, J_max=2, M=3, p_min=1, p_max=9, N_min=1, N_max=2, S=1, DDT=1.0)]
+    s8g = fi.InstanceSet(3)
+    for i, kw in enumerate(sod_prm):
+        seed = 6600 + i
+        s8g.generate(i, seed, fi.GenParams(t_si_min=100.0, t_si_max=200.0, **kw))
+        while not (s8g.arrays(i).p > 0).any(axis=0).all():        # class_FJSP.py:159 divides by len(kind_task_tuple)
+            seed += 7919
+            s8g.generate(i, seed, fi.GenParams(t_si_min=100.0, t_si_max=200.0, **kw))
+        write_csv_folder(s8g.arrays(i), os.path.join(tmp, "sod", "G%d" % i))
+        s8.load_csv(len(sod_cases) + i, os.path.join(tmp, "sod"), "G%d" % i)
+    s8.solve_fluid()
+    cases = [(d.split("/")[-1] + "/" + f, s8.arrays(i), REF + "/data/" + d, f) for i, (d, f) in enumerate(sod_cases)]
+    cases += [("gen%d" % (6600 + i), s8.arrays(len(sod_cases) + i), os.path.join(tmp, "sod"), "G%d" % i) for i in range(3)]
+    suite("so_dfjsp", cases,
+          lambda ci: [(("random",), 701 + ci, True), (("fixed", (3, 3)), 0, True), (("fixed", (0, 0)), 0, True),
+                      (("fixed", (4, 2)), 0, True)],
+          lambda ci: [] if args.quick else [(kp, 0) for kp in ALL_PAIRS[ci % 2::2]] + [(("random",), 801 + ci)],
+          full_state_eps={0}, variant="sod")
 
     report.append("LP checks vs HiGHS on the reference-built model: %d solves, max objective gap %.2e, max infeasibility %.2e"
                   % (LP_STATS["solves"], LP_STATS["max_obj_gap"], LP_STATS["max_infeas"]))

@@ -6,6 +6,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SUITES = ("mk01", "synth10x5", "multijob", "large", "edge", "multiorder")      # SO_FJSSP (multiorder: S > 1)
+SOD_SUITES = ("so_dfjsp",)                                   # SO_DFJSP (SO_FJSSP over class_FJSP.py: due date = order delivery)
 MO_SUITES = ("mo_discretes",)                                # MO_FJSSP_discretes
 SF_SUITES = ("so_sfjsp",)                                    # SO_SFJSP
 DYN_SUITES = ("mo_dfjsp",)                                   # MO_DFJSP_breakdown (order arrivals, breakdowns, energy)

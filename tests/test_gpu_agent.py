@@ -240,3 +240,30 @@ def test_da3c_and_sac_controller_on_mo_dfjsp(torch_gpu, tmp_path):
     assert ((st & ~4) == 0).all()
     rw = sac.memory.rewards[:len(sac.memory)]
     assert bool(torch.isfinite(rw).all()) and float(rw.max()) <= 0.0          # every objective only grows
+
+
+def test_da3c_on_so_dfjsp(torch_gpu):
+    """agents/DA3C/DA3C_double_actor.py: the same double-actor A2C at sizes 20 -> 6 / 21 -> 5 on its environment,
+    environments/SO_DFJSP.py (order arrivals, due date = order delivery)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedSODFJSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.A3C import DA3C
+    prm = fi.GenParams(R_min=3, R_max=4, J_min=2, J_max=3, M=5, p_min=5, p_max=40, N_min=1, N_max=3, S=2, DDT=1.0,
+                       t_si_min=100.0, t_si_max=200.0)
+    test_env = BatchedSODFJSP(fi.InstanceSet(6).generate_range(300, prm).solve_fluid(), rng_seed=2)
+    rounds = [0]
+
+    def make_train_env():
+        rounds[0] += 1
+        return BatchedSODFJSP(fi.InstanceSet(32).generate_range(5000 * rounds[0], prm).solve_fluid(), rng_seed=rounds[0])
+
+    torch.manual_seed(0)
+    tr = DA3C(make_train_env, test_env, reward_policy=None, hidden_size=32, hidden_layer=2, seed=1, max_steps=300,
+              state_size=20, actions_size=(6, 5))
+    before = [p.detach().clone() for p in tr.actor_task_model.parameters()]
+    objs = [tr.run_one_round() for _ in range(2)]
+    assert all(np.isfinite(o) and o >= 0 for o in objs) and all(np.isfinite(v) for v in tr.last_losses)
+    assert any(not torch.equal(b, p) for b, p in zip(before, tr.actor_task_model.parameters()))
+    assert tr.actor_machine_model.layers_2[0].in_features == 21 and tr.actor_task_model.layers_1[-1].out_features == 6
+

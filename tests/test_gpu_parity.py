@@ -29,7 +29,7 @@ def _batch_for(suite, torch):
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
     insts, eps, base = H.load_suite(suite)
     s = H.instance_set_from([insts[ep["inst"]] for ep in eps])
-    b = EnvBatch(s, len(eps), rng_seed=base)
+    b = EnvBatch(s, len(eps), rng_seed=base, variant=5 if suite in H.SOD_SUITES else 0)
     for e, ep in enumerate(eps):
         assert b.env_seed(e) == ep["rng_seed"]
     T = max(ep["T"] for ep in eps)
@@ -58,7 +58,7 @@ def test_fluid_tables_match_oracle(torch_gpu, suite):
             assert np.array_equal(H.bits(g), H.bits(w)), (suite, a.name, name)
 
 
-@pytest.mark.parametrize("suite", H.SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.SOD_SUITES)
 def test_step_kernel_matches_reference_fixtures(torch_gpu, suite):
     """Per-step launches through fjsp_env_step vs the stored reference traces."""
     torch = torch_gpu
@@ -95,7 +95,7 @@ def test_step_kernel_matches_reference_fixtures(torch_gpu, suite):
         assert (status[e] & 4 != 0) == (Te < T)
 
 
-@pytest.mark.parametrize("suite", H.SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.SOD_SUITES)
 def test_rollout_kernel_matches_reference_fixtures(torch_gpu, suite):
     """The fused T-step kernel: chosen (operation, machine) per step, rewards, final attributes."""
     torch = torch_gpu
@@ -450,7 +450,7 @@ def test_mo_dfjsp_full_size_batch_against_oracle_and_invariants(torch_gpu):
 
 
 @pytest.mark.parametrize("shape", ["small", "big", "jobs"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
 def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     """Beyond the committed reference traces: freshly generated instances of mixed shape -- "small": 96 x (1-6
     kinds, 1-4 stages, 1-12 machines, 1-4 jobs per kind), also shops with more machines than operation types;
@@ -469,7 +469,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     fuzz = int(os.environ.get("FJSP_FUZZ_SEED", "0"))          # tools/fuzz_parity.sh sweeps this
     rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70}[shape] + 1000 * fuzz)
     s = fi.InstanceSet(OFF + NI)
-    multi = variant in (0, 4)
+    multi = variant in (0, 4, 5)
     for i in range(OFF, OFF + NI):
         if shape == "jobs":      # few kinds, many jobs per kind (list positions, FIFO order, several job-table chunks)
             R = int(rs.randint(1, 5)); Jlo = int(rs.randint(2, 5)); M = int(rs.randint(2, 9)); nmax = int(rs.randint(20, 61))
@@ -482,7 +482,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
                            DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
         seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000}[shape] + 1000003 * fuzz
         s.generate(i, seed, prm)
-        while variant == 4 and not (s.arrays(i).p > 0).any(axis=0).all():      # the reference divides by zero there
+        while variant in (4, 5) and not (s.arrays(i).p > 0).any(axis=0).all():  # the reference divides by zero there
             seed += 7919
             s.generate(i, seed, prm)
         if variant == 4:
@@ -491,7 +491,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     inst_arrs = [s.arrays(OFF + i) for i in range(NI)]
     arrs = [inst_arrs[e % NI] for e in range(N)]              # env e plays instance first + e % n_inst
     T = max(int((a.count.sum(0) * a.Jr).sum()) for a in arrs)
-    n0, n1 = {0: (6, 5), 1: (20, 1), 2: (18, 1), 4: (12, 10)}[variant]
+    n0, n1 = {0: (6, 5), 1: (20, 1), 2: (18, 1), 4: (12, 10), 5: (6, 5)}[variant]
     actions_h = np.stack([rs.randint(0, n0, (T, N)), rs.randint(0, n1, (T, N))], 2).astype(np.uint8)
     actions = torch.from_numpy(actions_h).cuda()
     b = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=777 + variant)
@@ -516,7 +516,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
         rewards[t] = r.cpu().numpy(); states[t] = st.cpu().numpy()
     fin = {k: v.cpu().numpy() for k, v in b.read().items()}
     assert (fin["done"] == 1).all() and (fin["status"] & ~4 == 0).all()
-    kw = {0: {}, 1: dict(sf=True), 2: dict(mo=True), 4: dict(dyn=True)}[variant]
+    kw = {0: {}, 1: dict(sf=True), 2: dict(mo=True), 4: dict(dyn=True), 5: {}}[variant]
     for e, a in enumerate(arrs):
         want = H.play_oracle(a, a.x, actions_h[:, e], b.env_seed(e), variant=variant, mo=None if mo_rows is None else mo_rows[e])
         Te = want["T"]
@@ -550,7 +550,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     # autoreset: every env of `b` is done; a step with autoreset starts a fresh episode inside the launch (reset
     # observation taken from the per-instance cache) and must equal reset() + step() on a fresh batch.  A
     # deterministic rule pair is used (the random.choice stream continues across resets).
-    det = torch.tensor({0: (2, 0), 1: (0, 0), 2: (0, 0), 4: (2, 0)}[variant], dtype=torch.uint8).repeat(N, 1).cuda()
+    det = torch.tensor({0: (2, 0), 1: (0, 0), 2: (0, 0), 4: (2, 0), 5: (2, 0)}[variant], dtype=torch.uint8).repeat(N, 1).cuda()
     fresh = EnvBatch(s, N, first=OFF, n_inst=NI, variant=variant, rng_seed=5)
     fresh.reset()
     st_f, r_f, d_f = fresh.step(det, mo=mo)

@@ -10,7 +10,7 @@ import pytest
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("suite", H.SUITES + H.MO_SUITES + H.SF_SUITES + H.DYN_SUITES + H.ORACLE_ONLY_SUITES)
+@pytest.mark.parametrize("suite", H.SUITES + H.SOD_SUITES + H.MO_SUITES + H.SF_SUITES + H.DYN_SUITES + H.ORACLE_ONLY_SUITES)
 def test_oracle_matches_reference_fixtures(built, suite):
     insts, eps, _ = H.load_suite(suite)
     assert eps, "empty fixture"
@@ -26,7 +26,7 @@ def test_oracle_matches_reference_fixtures(built, suite):
             got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=1)
             assert got["completion_time"] == int(ep["completion"]) == int(ep["final"][0])
         else:
-            got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"])
+            got = H.play_oracle(a, a.x, ep["actions"], ep["rng_seed"], variant=5 if suite in H.SOD_SUITES else 0)
         tag = "%s episode %d (%s)" % (suite, e, a.name)
         assert got["T"] == ep["T"], tag
         for key in ("k", "m", "job_r", "job_n", "done", "step_time", "delay"):
