@@ -29,27 +29,29 @@ def main():
     from environments.MO_FJSSP_discretes import MO_FJSSP_Environment
     from environments.SO_SFJSP import SO_SFJSP_Environment
     from environments.MO_DFJSP_breakdown import MO_DFJSP_Environment
-    classes = {"so": SO_FJSSP_Environment, "mo": MO_FJSSP_Environment, "sf": SO_SFJSP_Environment, "dyn": MO_DFJSP_Environment}
-    flat = {"so": None, "mo": 18, "sf": 20, "dyn": "dyn"}
+    from environments.SO_DFJSP import SO_DFJSP_Environment
+    classes = {"so": SO_FJSSP_Environment, "mo": MO_FJSSP_Environment, "sf": SO_SFJSP_Environment, "dyn": MO_DFJSP_Environment,
+               "sod": SO_DFJSP_Environment}
+    flat = {"so": None, "mo": 18, "sf": 20, "dyn": "dyn", "sod": None}
     tmp = tempfile.mkdtemp(prefix="fjsp_fuzz_")
     rs = np.random.RandomState(args.seed)
     t_end = time.time() + args.seconds
     n_eps = n_steps = n_case = 0
     while time.time() < t_end:
-        variant = ("so", "mo", "sf", "dyn")[n_case % 4]
-        shape = ("small", "big", "jobs")[(n_case // 4) % 3]
+        variant = ("so", "mo", "sf", "dyn", "sod")[n_case % 5]
+        shape = ("small", "big", "jobs")[(n_case // 5) % 3]
         if shape == "jobs":
             R = int(rs.randint(1, 5)); Jlo = int(rs.randint(2, 5)); M = int(rs.randint(2, 9)); nmax = int(rs.randint(10, 41))
         elif shape == "big":
             R = int(rs.randint(8, 20)); Jlo = int(rs.randint(3, 7)); M = int(rs.randint(8, 33)); nmax = int(rs.randint(1, 3))
         else:
             R = int(rs.randint(1, 7)); Jlo = int(rs.randint(1, 4)); M = int(rs.randint(1, 13)); nmax = int(rs.randint(1, 5))
-        S = int(rs.randint(1, 4)) if variant in ("so", "dyn") else 1
+        S = int(rs.randint(1, 4)) if variant in ("so", "dyn", "sod") else 1
         prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=1, p_max=int(rs.randint(2, 60)),
                            N_min=1, N_max=nmax, S=S, DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
         seed = int(rs.randint(1, 1 << 30))
         g = fi.InstanceSet(1).generate(0, seed, prm)
-        while variant == "dyn" and not (g.arrays(0).p > 0).any(axis=0).all():
+        while variant in ("dyn", "sod") and not (g.arrays(0).p > 0).any(axis=0).all():
             seed += 7919
             g.generate(0, seed, prm)
         if variant == "dyn":
@@ -64,8 +66,8 @@ def main():
             rng_seed = int(rs.randint(1, 1 << 62))
             if variant == "so":
                 mo = None
-            elif variant == "sf":
-                mo = "sf"
+            elif variant in ("sf", "sod"):
+                mo = variant
             elif variant == "mo":
                 mo = (0.5, 0.5, 37.0, 91.0) if rep else (0.0, 1.0, None, None)
             else:
