@@ -449,7 +449,7 @@ def test_mo_dfjsp_full_size_batch_against_oracle_and_invariants(torch_gpu):
         assert fin["energy_consumption"][e] == want["energy"] and fin["completion_time"][e] == want["completion_time"], e
 
 
-@pytest.mark.parametrize("shape", ["small", "big", "jobs"])
+@pytest.mark.parametrize("shape", ["small", "big", "jobs", "long"])
 @pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
 def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     """Beyond the committed reference traces: freshly generated instances of mixed shape -- "small": 96 x (1-6
@@ -463,24 +463,28 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     from deep_reinforcement_learning_for_fjsp_amd import instances as fi
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
     big = shape == "big"
-    NI = {"small": 96, "big": 24, "jobs": 32}[shape]           # instances; they sit at an offset inside the set
+    NI = {"small": 96, "big": 24, "jobs": 32, "long": 48}[shape]           # instances; they sit at an offset inside the set
     OFF = 2
     N = NI + NI // 4                                           # environments: the last quarter shares instances
     fuzz = int(os.environ.get("FJSP_FUZZ_SEED", "0"))          # tools/fuzz_parity.sh sweeps this
-    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70}[shape] + 1000 * fuzz)
+    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70, "long": 90}[shape] + 1000 * fuzz)
     s = fi.InstanceSet(OFF + NI)
     multi = variant in (0, 4, 5)
     for i in range(OFF, OFF + NI):
-        if shape == "jobs":      # few kinds, many jobs per kind (list positions, FIFO order, several job-table chunks)
+        pmin, pmax = 1, int(rs.randint(2, 60))
+        if shape == "long":      # one job per kind, processing times near the u16 limit: clocks beyond 2^22
+            R = int(rs.randint(20, 41)); Jlo = int(rs.randint(3, 6)); M = int(rs.randint(2, 5)); nmax = 1
+            pmin, pmax = 30000, 65535
+        elif shape == "jobs":      # few kinds, many jobs per kind (list positions, FIFO order, several job-table chunks)
             R = int(rs.randint(1, 5)); Jlo = int(rs.randint(2, 5)); M = int(rs.randint(2, 9)); nmax = int(rs.randint(20, 61))
         elif big:
             R = int(rs.randint(8, 25)); Jlo = int(rs.randint(3, 8)); M = int(rs.randint(8, 33)); nmax = int(rs.randint(1, 4))
         else:
             R = int(rs.randint(1, 7)); Jlo = int(rs.randint(1, 4)); M = int(rs.randint(1, 13)); nmax = int(rs.randint(1, 5))
-        prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=1, p_max=int(rs.randint(2, 60)),
+        prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=pmin, p_max=pmax,
                            N_min=1, N_max=nmax, S=int(rs.randint(1, 4)) if multi else 1,
                            DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
-        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000}[shape] + 1000003 * fuzz
+        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000, "long": 37000}[shape] + 1000003 * fuzz
         s.generate(i, seed, prm)
         while variant in (4, 5) and not (s.arrays(i).p > 0).any(axis=0).all():  # the reference divides by zero there
             seed += 7919
