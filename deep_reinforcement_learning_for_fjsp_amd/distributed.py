@@ -36,7 +36,8 @@ def init_from_env(backend=None):
         return
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # FJSP_DIST_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
+        backend = os.environ.get("FJSP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

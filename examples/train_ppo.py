@@ -29,7 +29,7 @@ def main():
 
     fd.init_from_env()
     rank, world = fd.rank(), fd.world_size()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     N = args.envs_per_gpu
     insts = fi.InstanceSet(N).generate_range(1000 + rank * N, fi.bench_10x5_params()).solve_fluid()
