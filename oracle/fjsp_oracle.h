@@ -6,12 +6,15 @@
  * environment:
  *     environments/SO_FJSSP.py:51-389        (reset / step / rules / state)
  *     environments/class_FJSSP.py:13-306     (object model, due dates, fluid parameters)
+ *     environments/SO_SFJSP.py, MO_FJSSP_discretes.py, SO_DFJSP.py (+ class_FJSP.py),
+ *     MO_DFJSP_breakdown.py (+ class_MODFJSP.py)   (the variants of fjo_create)
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this.  The product path (deep_reinforcement_learning_for_fjsp_amd)
  * never does; it fails loudly when the HIP library is missing.
  *
  * Parity status: pinned downstream of the fluid LP solution x (golden vectors
- * generated from the reference itself, tests/golden/make_golden.py);
+ * generated from the reference itself, tests/golden/make_golden.py: 3 061
+ * episodes; plus 11 696 random-shape episodes, fuzz_oracle_vs_reference.py);
  * "parity unpinned" AT the LP boundary (docplex/CPLEX absent, optimum
  * non-unique) -- x is an input here.
  */
