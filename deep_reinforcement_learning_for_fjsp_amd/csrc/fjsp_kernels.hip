@@ -381,6 +381,33 @@ template <int KC, int V>
 __device__ __forceinline__ void compute_params(W<KC, V> &w) {
     const int t = w.t;
     const double td = (double)t;
+    // one job per kind (10x5, the Brandimarte sets): every list has at most one member, so the walk below is a
+    // handful of selects -- no loop, no divergent branches
+    bool single_job = !is_mord_v<V>;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) single_job = single_job && __ballot((w.kA[c] >> 16) > 1u) == 0;
+    if (single_job) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const uint32_t a = w.kA[c];
+            const int jbeg = (int)(a & 0xFFFFu), j = (int)(w.kB[c] & 0xFFu);
+            const bool has = (a >> 16) != 0;
+            const uint32_t js = w.jstL[jbeg];
+            const int d = w.dueL[jbeg];
+            const int nj = (int)(js & 0xFFu);
+            const bool in = has && nj <= j;                             // the job's stage-j task is still unassigned
+            const int da = t - d;                                       // :138
+            const double est = td + w.time_sum[c];                      // :136,139 with task_index 0
+            const double de = est - (double)d;
+            const bool late = in && t > d;
+            const bool waiting = in && nj == j && (js >> 8) != kNoSeq;
+            w.nun[c] = in; w.cnt_a[c] = late; w.tard[c] = late ? da : 0;
+            w.cnt_e[c] = in && est > (double)d;
+            w.max_a[c] = in ? da : 0; w.max_e[c] = in ? de : 0.0; w.sum_e[c] = in ? de : 0.0;   // (0.0 + de == de)
+            w.fifo_cnt[c] = waiting; w.head_job[c] = waiting ? jbeg : -1; w.due_min[c] = waiting ? d : 0x7fffffff;
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const uint32_t a = w.kA[c];
