@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
 
 // T fused steps per launch: the environment lives in registers + LDS for the whole episode.
 template <int KC, int V>
-__global__ __launch_bounds__(256) void rollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T,
+__global__ __launch_bounds__(256, (KC == 1 && V == FJSP_VARIANT_SO_FJSSP) ? 4 : 1) void rollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T,
                                                       int16_t *trace_km, double *reward_out, double *state_last) {
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env = blockIdx.x * (blockDim.x >> 6) + wave;
