@@ -732,16 +732,32 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         if (l.asc) { uint32_t m = l.mask; while (m) { f((int)__builtin_ctz(m)); m &= m - 1; } }
         else for (int i = 0; i < l.n; ++i) f((int)((l.packed >> (8 * i)) & 0xFFu));
     };
-    auto argmax_gap = [&](const CandList &l) __attribute__((always_inline)) {
+    // a candidate list in ascending order (always the case for M <= 8) is a lane mask: the rule is then the same
+    // wave reduction + first-set-bit ballot as the task rules; the CPython-ordered short lists are walked
+    auto lane_argmax_f64 = [&](const CandList &l, double key) __attribute__((always_inline)) {
+        if (l.n == 1) return (int)__builtin_ctz(l.mask);
+        if (l.asc) {
+            const uint64_t m64[1] = {(uint64_t)l.mask};
+            const double k1[1] = {key};
+            return argmax_f64<1>(m64, k1);
+        }
         int best = -1; double bv = 0.0;
-        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(g, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(key, m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
-    auto argmin_p = [&](const CandList &l) __attribute__((always_inline)) {
+    auto lane_argmin_i32 = [&](const CandList &l, int key) __attribute__((always_inline)) {
+        if (l.n == 1) return (int)__builtin_ctz(l.mask);
+        if (l.asc) {
+            const uint64_t m64[1] = {(uint64_t)l.mask};
+            const int k1[1] = {key};
+            return argext_i32<1, false>(m64, k1);
+        }
         int best = -1, bv = 0;
-        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(pm, m); if (best < 0 || v < bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(key, m); if (best < 0 || v < bv) { bv = v; best = m; } });
         return best;
     };
+    auto argmax_gap = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmax_f64(l, g); };
+    auto argmin_p = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmin_i32(l, pm); };
     auto argmax_gave = [&](const CandList &l) __attribute__((always_inline)) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
         // gap_ave of every candidate, three per pass, parked in the candidate's machine lane
@@ -757,15 +773,9 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
             for (int q = 0; q < 3; ++q)
                 if (mq[q] >= 0 && w.lane == mq[q]) gave_m = rld(v, q);
         }
-        int best = -1; double bv = 0.0;
-        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(gave_m, m); if (best < 0 || v > bv) { bv = v; best = m; } });
-        return best;
+        return lane_argmax_f64(l, gave_m);
     };
-    auto argmin_lane = [&](const CandList &l, int key) __attribute__((always_inline)) {          // first minimum of a machine-lane integer
-        int best = -1, bv = 0;
-        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(key, m); if (best < 0 || v < bv) { bv = v; best = m; } });
-        return best;
-    };
+    auto argmin_lane = [&](const CandList &l, int key) __attribute__((always_inline)) { return lane_argmin_i32(l, key); };
     int m_sel;
     if (V == kDyn) {
         const CandList &fl = fsel.n ? fsel : sel;
