@@ -14,7 +14,7 @@
  *
  * Parity status: pinned downstream of the fluid LP solution x (golden vectors
  * generated from the reference itself, tests/golden/make_golden.py: 3 061
- * episodes; plus 11 696 random-shape episodes, fuzz_oracle_vs_reference.py);
+ * episodes; plus 19 752 random-shape episodes, fuzz_oracle_vs_reference.py);
  * "parity unpinned" AT the LP boundary (docplex/CPLEX absent, optimum
  * non-unique) -- x is an input here.
  */
