@@ -45,7 +45,8 @@ struct EnvScalars {
     int64_t delay_sum;       // delay_time_sum == delay_time_sum_last after a step (:44,263)
     int32_t t_arr;           // self.order_arrive_time                  (:19)
     int16_t next_order;      // index of the first order not yet arrived (order_object_list, :53-56)
-    int16_t pending;         // 1 = the event loop stopped at an order arrival and waits for its fluid LP
+    int8_t pending;          // 1 = the event loop stopped at an order arrival and waits for its fluid LP
+    int8_t obs_stale;        // 1 = obs_prev is not the observation of the current state (steps that handed no state back)
     double obs_prev[10];     // observation_state v(t)                  (:21)
 };
 static_assert(sizeof(EnvScalars) == 18 * 8, "EnvScalars must be 18 words");

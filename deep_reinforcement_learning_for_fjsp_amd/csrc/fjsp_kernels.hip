@@ -59,6 +59,9 @@ template <int V>
 constexpr bool is_so_v = (V == FJSP_VARIANT_SO_FJSSP || V == kMord);
 template <int V>
 constexpr bool is_mord_v = (V == kMord || V == kDyn);
+#ifndef FJSP_SHARED_TAIL
+#define FJSP_SHARED_TAIL 1
+#endif
 constexpr uint32_t kAbsent = 0xFFu;      // next_stage of a job whose order has not arrived yet
 
 // ------------------------------------------------------------------ diagnostics
@@ -66,18 +69,18 @@ constexpr uint32_t kAbsent = 0xFFu;      // next_stage of a job whose order has 
 // every wave adds the s_memtime delta of each phase of a step to a global table.
 #ifdef FJSP_STAMPS
 __device__ unsigned long long fjsp_stamp_acc[16];
-#define STAMP_FIELDS unsigned long long st[10]; unsigned long long st_t0;
-#define STAMP_BEGIN(w) do { for (int _i = 0; _i < 10; ++_i) (w).st[_i] = 0; (w).st_t0 = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_FIELDS unsigned long long st[14]; unsigned long long st_t0;
+#define STAMP_BEGIN(w) do { for (int _i = 0; _i < 14; ++_i) (w).st[_i] = 0; (w).st_t0 = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP(w, slot)                                                      \
     do {                                                                    \
-        const unsigned long long _t1 = __builtin_amdgcn_s_memrealtime();        \
+        const unsigned long long _t1 = __builtin_amdgcn_s_memtime();            \
         (w).st[slot] += _t1 - (w).st_t0;                                    \
         (w).st_t0 = _t1;                                                    \
     } while (0)
 #define STAMP_FLUSH(w)                                                                      \
     do {                                                                                    \
         if (__lane_id() == 0) {                                                             \
-            for (int _i = 0; _i < 10; ++_i) atomicAdd(&fjsp_stamp_acc[_i], (w).st[_i]);     \
+            for (int _i = 0; _i < 14; ++_i) atomicAdd(&fjsp_stamp_acc[_i], (w).st[_i]);     \
             atomicAdd(&fjsp_stamp_acc[15], 1ull);                                           \
         }                                                                                   \
     } while (0)
@@ -97,6 +100,11 @@ __device__ __forceinline__ double rld(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// lane `l` (a constant) of `vec` := the wave-uniform `sval` (v_writelane_b32; this clang has no builtin for it)
+__device__ __forceinline__ int wlane(int sval, int l, int vec) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(__builtin_amdgcn_readfirstlane(sval)), "n"(l));
+    return vec;
+}
 __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // Hand-off of LDS data between lanes of one wave.  LDS operations of a wave execute
 // in order, so only the compiler has to be kept from moving LDS accesses across the
@@ -113,29 +121,79 @@ __device__ __forceinline__ void wave_sync_global() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-extern __shared__ unsigned char fjsp_lds[];
+extern __shared__ __attribute__((aligned(16))) unsigned char fjsp_lds[];
 
-// Strictly sequential float sum of n8 (a multiple of 8) operands held in LDS, left to right like
-// the reference's sum() (SO_FJSSP.py:86-95): (((0 + x0) + x1) + ...).  Operands are fetched 8 at a
-// time with the next batch in flight while the current one is consumed, so the chain pays the f64
-// add latency, not the LDS latency.  Entries past the real length hold +0.0, which is an exact
-// identity here (the running sum starts at +0.0 and can never become -0.0).
-__device__ __forceinline__ double lds_chain_sum(uint32_t lds_byte_offset, int n8) {
-    const double *src = reinterpret_cast<const double *>(fjsp_lds + lds_byte_offset);
-    double acc = 0.0, cur[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) cur[q] = src[q];
-    for (int i = 8; i < n8; i += 8) {
-        double nxt[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nxt[q] = src[i + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = acc + cur[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+// Strictly sequential float sum of n8 (a multiple of 8, >= 8) operands held in LDS, left to right like
+// the reference's sum() (SO_FJSSP.py:86-95): (((0 + x0) + x1) + ...).  The chain itself costs 8 cycles per
+// dependent v_add_f64; what made it 40-54 cycles per element (tools/ubench/lds_chain.hip) was the LDS pipe: a
+// wave-wide read occupies it for the full 64 lanes even when three of them carry useful data.  So: 16-byte
+// reads (ds_read_b128: two operands per lane at half the pipe time of ds_read2_b64), rows skewed by 16 bytes
+// so that the rows walked side by side sit in different banks, and a ring of 16-byte registers refilled
+// a ring's length ahead, so the adds never wait for the LDS.  Entries past the real length hold +0.0, which is an
+// exact identity here (the running sum starts at +0.0 and can never become -0.0); the ring reads up to 2 RING
+// entries past n8: rows are followed by at least 128 bytes of the same LDS slice.  `src` is 16-byte aligned.
+// The compiler's scheduler sinks the refills of such a ring behind all the adds of a turn (and then waits for
+// them), so the walker of step_kernel -- alone on its SIMD while it walks, nothing else hides the LDS for it --
+// uses the form below: the reads and the waits are volatile asm statements (they keep their order), each wait
+// carries the register it waits for as an in/out operand (so the adds that consume it cannot move above it),
+// and the register allocation stays the compiler's: eight 16-byte registers, each refilled 16 elements ahead
+// right after its two operands are consumed; s_waitcnt lgkmcnt(7) waits for exactly the oldest read.
+typedef double fjsp_d2 __attribute__((ext_vector_type(2)));
+#define FJSP_LDS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define FJSP_LDS_WAIT(reg, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(cnt))
+__device__ __forceinline__ double lds_chain_sum_ring8(const double *src, int n8) {
+    double acc = 0.0;
+    uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(src);      // the low half of a flat LDS address is the LDS offset
+    const int n = __builtin_amdgcn_readfirstlane(n8);
+    fjsp_d2 A0, A1, A2, A3, A4, A5, A6, A7;
+    FJSP_LDS_READ128(A0, a, 0); FJSP_LDS_READ128(A1, a, 16); FJSP_LDS_READ128(A2, a, 32); FJSP_LDS_READ128(A3, a, 48);
+    FJSP_LDS_READ128(A4, a, 64); FJSP_LDS_READ128(A5, a, 80); FJSP_LDS_READ128(A6, a, 96); FJSP_LDS_READ128(A7, a, 112);
+    int i = 0;
+#define FJSP_RING_STEP(R, off) FJSP_LDS_WAIT(R, 7); acc = acc + R.x; acc = acc + R.y; FJSP_LDS_READ128(R, a, off);
+    for (; i + 16 <= n; i += 16) {       // whole turns: every register is refilled (unconditionally) once consumed
+        FJSP_RING_STEP(A0, 128) FJSP_RING_STEP(A1, 144) FJSP_RING_STEP(A2, 160) FJSP_RING_STEP(A3, 176)
+        FJSP_RING_STEP(A4, 192) FJSP_RING_STEP(A5, 208) FJSP_RING_STEP(A6, 224) FJSP_RING_STEP(A7, 240)
+        a += 128;
     }
+#undef FJSP_RING_STEP
+    // drain: the refills of the last turn are never consumed, but they must have landed before their registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
+    if (i < n) {                         // n is a multiple of 8: eight operands left, in the first half of the ring
+        acc = acc + A0.x; acc = acc + A0.y; acc = acc + A1.x; acc = acc + A1.y;
+        acc = acc + A2.x; acc = acc + A2.y; acc = acc + A3.x; acc = acc + A3.y;
+    }
+    return acc;
+}
+
+// RING = registers of the ring of the compiler-scheduled form (kernels whose waves each walk their own rows and
+// hide the LDS behind one another).
+template <int RING>
+__device__ __forceinline__ double lds_chain_sum(const double *src, int n8) {
+    if constexpr (RING == 8) return lds_chain_sum_ring8(src, n8);
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double acc = 0.0;
+    double2 A[RING];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc = acc + cur[q];
+    for (int q = 0; q < RING; ++q) A[q] = s2[q];
+    int i = 0;
+    // whole turns of the ring: every register is refilled, unconditionally (no branches, no copies), as soon as
+    // its two operands are consumed
+    for (; i + 2 * RING <= n8; i += 2 * RING) {
+#pragma unroll
+        for (int q = 0; q < RING; ++q) {
+            acc = acc + A[q].x; acc = acc + A[q].y;
+            A[q] = s2[i / 2 + RING + q];
+        }
+    }
+    // n8 is a multiple of 8: what is left is a multiple of 8 below 2 RING, already in the ring
+#pragma unroll
+    for (int h = 0; h < RING / 4; ++h) {
+        if (i < n8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc = acc + A[4 * h + q].x; acc = acc + A[4 * h + q].y; }
+            i += 8;
+        }
+    }
     return acc;
 }
 
@@ -196,6 +254,7 @@ struct W {
     long long tard_done, delay_sum;
     uint64_t env_seed;
     int t_arr, next_order, pending, n_orders;      // order arrivals (multi-order batches)
+    int obs_stale;                                 // obs_prev_l is not v(t-1) (EnvScalars::obs_stale)
     long long energy, energy_last;                 // MO_DFJSP: energy_consumption(_last)
     const unsigned char *ir;
     // lane = operation type
@@ -212,7 +271,8 @@ struct W {
     // wave-private LDS
     uint32_t *jstL;
     int32_t *dueL;
-    double *scrL;   // 16 doubles: the observation being assembled
+    double *scrL;   // 16 doubles: the observation being assembled (slot 15: mean of the machines' time_end)
+    int32_t *hdrL;  // 16 ints: what the observation tail needs of this environment (TailHdr)
     double *frL, *grL, *tdL;   // serial-sum operands: finish_rate[KP], gap_rate[KP], time_end[KP] (zero padded)
     double *unp;    // unprocessed_rj matrix [KP][MP] (op-major): LDS slice (rollout) or the env record (step)
     // rows of this instance / env record
@@ -225,7 +285,11 @@ struct W {
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, bool un_lds) {
-    return (size_t)(16 + 3 * KP) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 8;
+    // [obs 16][tail header 8][3 rows of KP + 2 doubles (16-byte skew: lds_chain_sum)][un][jst, due], then padded so that
+    // consecutive slices start 64 bytes apart modulo the 256-byte bank period: the walker of step_kernel reads
+    // the rows of four slices side by side
+    const size_t raw = (size_t)(24 + 3 * (KP + 2)) * 8 + (un_lds ? (size_t)MP * KP * 8 : 0) + (size_t)JP * 8;
+    return raw + (size_t)((64 + 256 - (int)(raw % 256)) % 256);
 }
 
 // Bind the wave to its records and bring the environment in.  All loads below are
@@ -239,16 +303,17 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn;
     w.env = env;
     w.lane = (int)__lane_id();
-    w.inst = env % b->n_inst;
+    w.inst = b->n_inst == b->N ? env : env % b->n_inst;     // (one instance per environment: no division)
     const int JP = b->JP, KP = b->KP, MP = b->MP;
     const Layout &L = b->L;
     const unsigned char *ir = b->inst + (size_t)w.inst * L.i_stride;
     unsigned char *er = b->envs + (size_t)env * L.e_stride;
     w.er = er;
-    // LDS carve: [obs 16][fr KP][gr KP][td KP][un (optional)][jst][due]
+    // LDS carve: [obs 16][tail header 16 x i32][fr KP][gr KP][td KP][un (optional)][jst][due]
     w.scrL = reinterpret_cast<double *>(lds);
-    w.frL = w.scrL + 16; w.grL = w.frL + KP; w.tdL = w.grL + KP;
-    unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + KP);
+    w.hdrL = reinterpret_cast<int32_t *>(w.scrL + 16);
+    w.frL = w.scrL + 24; w.grL = w.frL + KP + 2; w.tdL = w.grL + KP + 2;
+    unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + KP + 2);
     if (un_lds) { w.unp = reinterpret_cast<double *>(q); q += (size_t)MP * KP * 8; }
     else w.unp = reinterpret_cast<double *>(er + L.e_un);
     w.jstL = reinterpret_cast<uint32_t *>(q); q += (size_t)JP * 4;
@@ -288,7 +353,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         sc.status = es->status; sc.seq_ctr = es->seq_ctr; sc.rng_calls = es->rng_calls; sc.busy = es->busy;
         sc.completion = es->completion; sc.completion_last = es->completion_last;
         sc.tard_done = es->tard_done; sc.delay_sum = es->delay_sum;
-        sc.t_arr = es->t_arr; sc.next_order = es->next_order; sc.pending = es->pending;
+        sc.t_arr = es->t_arr; sc.next_order = es->next_order; sc.pending = es->pending; sc.obs_stale = es->obs_stale;
         if (w.lane < 10) obs0 = es->obs_prev[w.lane];
         if (w.lane < MP) {
             tend0 = reinterpret_cast<const int32_t *>(er + L.e_tend)[w.lane];
@@ -305,7 +370,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.pw_i = reinterpret_cast<const uint16_t *>(ir + (V == kDyn ? L.i_pw : L.i_p));
     w.col_i = reinterpret_cast<const double *>(is_mord_v<V> ? er + L.e_col : ir + L.i_col);
     w.ir = ir;
-    w.t_arr = 0; w.next_order = 1; w.pending = 0;
+    w.t_arr = 0; w.next_order = 1; w.pending = 0; w.obs_stale = 0;
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
     w.sstate = reinterpret_cast<const double *>(ir + L.i_ss);
     w.fluid_completed_time = w.sstate[7];
@@ -329,6 +394,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.completion = uni(sc.completion); w.completion_last = uni(sc.completion_last);
     w.tard_done = sc.tard_done; w.delay_sum = sc.delay_sum;
     w.t_arr = uni(sc.t_arr); w.next_order = uni((int)sc.next_order); w.pending = uni((int)sc.pending);
+    w.obs_stale = uni((int)sc.obs_stale);
     w.obs_prev_l = obs0;
     w.tend_m = w.lane < w.M ? tend0 : 0;
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
@@ -350,7 +416,7 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
         es->status = w.status; es->seq_ctr = w.seq_ctr; es->rng_calls = w.rng_calls; es->busy = w.busy;
         es->completion = w.completion; es->completion_last = w.completion_last;
         es->tard_done = w.tard_done; es->delay_sum = w.delay_sum;
-        es->t_arr = w.t_arr; es->next_order = (int16_t)w.next_order; es->pending = (int16_t)w.pending;
+        es->t_arr = w.t_arr; es->next_order = (int16_t)w.next_order; es->pending = (int8_t)w.pending; es->obs_stale = (int8_t)w.obs_stale;
     }
     if (w.lane < 10) reinterpret_cast<EnvScalars *>(er)->obs_prev[w.lane] = w.obs_prev_l;
     if (w.lane < w.M) {
@@ -665,12 +731,12 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
 // running sum) go to the three LDS operand rows and lanes 0..2 walk one row each, so the chains cost one
 // LDS read + one add per element instead of a ballot/readlane walk per machine.  Machine ids < 0 are
 // skipped.  Returns, in lane q < 3, the gap_ave of machine mq.
-template <int KC, int V>
+template <int KC, int V, int RING>
 __device__ __forceinline__ double gap_ave3(const W<KC, V> &w, int m0, int m1, int m2) {
     const double dt = fluid_dt(w);
     const int n8 = (w.K + 7) & ~7;
-    const uint32_t src_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.frL) - fjsp_lds) +
-                             (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));
+    // (offset arithmetic, not a select between the pointer fields of `w`: that would pin `w` in scratch)
+    const double *src = w.frL + (w.lane == 1 ? w.KP + 2 : (w.lane == 2 ? 2 * (w.KP + 2) : 0));
     int cnt_q[3] = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -679,22 +745,22 @@ __device__ __forceinline__ double gap_ave3(const W<KC, V> &w, int m0, int m1, in
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int k = c * kWave + w.lane;
-            int pm = 0;
+            // (r, j) is one of machine m's operation types iff m is in machine_rj_dict[(r, j)]: the eligibility mask
+            // this lane already holds (no look-up of the processing time)
+            const bool on_m = m >= 0 && ((w.elig[c] >> (m & 31)) & 1u) != 0;
             double g = 0.0;
-            if (m >= 0) {
+            // (uniform: the machine ids are wave-uniform)
+            if (on_m) {
                 const int o = k * w.MP + m;
-                pm = w.p_i[o];
-                if (pm > 0) {
-                    const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
-                    g = w.unp[o] - (ar.x - dt * ar.y);
-                }
+                const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
+                g = w.unp[o] - (ar.x - dt * ar.y);
             }
             row[k] = g;
-            cnt_q[q] += __builtin_popcountll(__ballot(pm > 0));
+            cnt_q[q] += __builtin_popcountll(__ballot(on_m));
         }
     }
     wave_sync();
-    const double sm = lds_chain_sum(src_off, n8);
+    const double sm = lds_chain_sum<RING>(src, n8);
     wave_sync();
     const int n = w.lane == 0 ? cnt_q[0] : (w.lane == 1 ? cnt_q[1] : cnt_q[2]);
     if (V == kDyn) return sm / (double)n;             // class_MODFJSP.py:158-159 has no epsilon
@@ -703,7 +769,7 @@ __device__ __forceinline__ double gap_ave3(const W<KC, V> &w, int m0, int m1, in
 
 // SO_FJSSP.py:300-322 machine_select.  Candidate lists are visited in CPython's
 // list(set & set) order (fjsp_pyset.h): ascending for M <= 8, not always beyond.
-template <int KC, int V>
+template <int KC, int V, int RING>
 __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, uint32_t idle, int *p_sel, double *un_sel,
                                               int *en_sel) {
     const int cs = k_sel >> 6, ls = k_sel & 63;
@@ -718,46 +784,44 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
     if (w.lane < w.M && ((sel.mask >> w.lane) & 1u)) {
         // op-major layout: the column of k_sel is MP contiguous entries per array (a handful of cache lines)
         const int o = k_sel * w.MP + w.lane;
-#if defined(FJSP_ABLATE) && FJSP_ABLATE == 6
-        pm = 1 + w.lane; un = 0.5; g = 0.25 * w.lane; (void)o;        // diagnostic: no column gather
-#else
         pm = w.p_i[o];
         un = w.unp[o];
         const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
         g = un - (ar.x - fluid_dt(w) * ar.y);
         if (V == kDyn) en = pm * (int)w.pw_i[o];                 // energy_mrj_dict class_MODFJSP.py:178
-#endif
     }
+    constexpr int base = 0;
     auto visit = [&](const CandList &l, auto &&f) __attribute__((always_inline)) {
         if (l.asc) { uint32_t m = l.mask; while (m) { f((int)__builtin_ctz(m)); m &= m - 1; } }
         else for (int i = 0; i < l.n; ++i) f((int)((l.packed >> (8 * i)) & 0xFFu));
     };
     // a candidate list in ascending order (always the case for M <= 8) is a lane mask: the rule is then the same
-    // wave reduction + first-set-bit ballot as the task rules; the CPython-ordered short lists are walked
-    auto lane_argmax_f64 = [&](const CandList &l, double key) __attribute__((always_inline)) {
+    // wave reduction + first-set-bit ballot as the task rules; the CPython-ordered short lists are walked.
+    // `at` = the lane that holds machine 0's key.
+    auto lane_argmax_f64 = [&](const CandList &l, double key, int at) __attribute__((always_inline)) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
         if (l.asc) {
-            const uint64_t m64[1] = {(uint64_t)l.mask};
+            const uint64_t m64[1] = {(uint64_t)l.mask << at};
             const double k1[1] = {key};
-            return argmax_f64<1>(m64, k1);
+            return argmax_f64<1>(m64, k1) - at;
         }
         int best = -1; double bv = 0.0;
-        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(key, m); if (best < 0 || v > bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const double v = rld(key, at + m); if (best < 0 || v > bv) { bv = v; best = m; } });
         return best;
     };
-    auto lane_argmin_i32 = [&](const CandList &l, int key) __attribute__((always_inline)) {
+    auto lane_argmin_i32 = [&](const CandList &l, int key, int at) __attribute__((always_inline)) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
         if (l.asc) {
-            const uint64_t m64[1] = {(uint64_t)l.mask};
+            const uint64_t m64[1] = {(uint64_t)l.mask << at};
             const int k1[1] = {key};
-            return argext_i32<1, false>(m64, k1);
+            return argext_i32<1, false>(m64, k1) - at;
         }
         int best = -1, bv = 0;
-        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(key, m); if (best < 0 || v < bv) { bv = v; best = m; } });
+        visit(l, [&](int m) __attribute__((always_inline)) { const int v = rl(key, at + m); if (best < 0 || v < bv) { bv = v; best = m; } });
         return best;
     };
-    auto argmax_gap = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmax_f64(l, g); };
-    auto argmin_p = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmin_i32(l, pm); };
+    auto argmax_gap = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmax_f64(l, g, base); };
+    auto argmin_p = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmin_i32(l, pm, base); };
     auto argmax_gave = [&](const CandList &l) __attribute__((always_inline)) {
         if (l.n == 1) return (int)__builtin_ctz(l.mask);
         // gap_ave of every candidate, three per pass, parked in the candidate's machine lane
@@ -768,14 +832,15 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (rest) { mq[q] = (int)__builtin_ctz(rest); rest &= rest - 1; }
-            const double v = gap_ave3<KC, V>(w, mq[0], mq[1], mq[2]);
+            const double v = gap_ave3<KC, V, RING>(w, mq[0], mq[1], mq[2]);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (mq[q] >= 0 && w.lane == mq[q]) gave_m = rld(v, q);
         }
-        return lane_argmax_f64(l, gave_m);
+        return lane_argmax_f64(l, gave_m, 0);
     };
-    auto argmin_lane = [&](const CandList &l, int key) __attribute__((always_inline)) { return lane_argmin_i32(l, key); };
+    auto argmin_en = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmin_i32(l, en, base); };
+    auto argmin_ipw = [&](const CandList &l) __attribute__((always_inline)) { return lane_argmin_i32(l, w.ipw_m, 0); };
     int m_sel;
     if (V == kDyn) {
         const CandList &fl = fsel.n ? fsel : sel;
@@ -784,10 +849,10 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         case 1: m_sel = argmin_p(fl); break;
         case 2: m_sel = argmin_p(sel); break;
         case 3: m_sel = argmax_gave(fl); break;
-        case 4: m_sel = argmin_lane(fl, en); break;               // rule 5: least processing energy, fluid first
-        case 5: m_sel = argmin_lane(sel, en); break;
-        case 6: m_sel = argmin_lane(fl, w.ipw_m); break;          // rule 7: least idle power, fluid first
-        case 7: m_sel = argmin_lane(sel, w.ipw_m); break;
+        case 4: m_sel = argmin_en(fl); break;                     // rule 5: least processing energy, fluid first
+        case 5: m_sel = argmin_en(sel); break;
+        case 6: m_sel = argmin_ipw(fl); break;                    // rule 7: least idle power, fluid first
+        case 7: m_sel = argmin_ipw(sel); break;
         case 8: m_sel = cand_at(fl, rng_choice(w, fl.n)); break;
         case 9: m_sel = cand_at(sel, rng_choice(w, sel.n)); break;
         default:
@@ -826,9 +891,9 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
             return -1;
         }
     }
-    *p_sel = rl(pm, m_sel);
-    *un_sel = rld(un, m_sel);
-    if (V == kDyn) *en_sel = rl(en, m_sel);
+    *p_sel = rl(pm, base + m_sel);
+    *un_sel = rld(un, base + m_sel);
+    if (V == kDyn) *en_sel = rl(en, base + m_sel);
     return m_sel;
 }
 
@@ -964,17 +1029,52 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
     wave_sync();
 }
 
-// SO_FJSSP.py:78-97 state_extract (+ the ratios of update_parameter :156-165).
-// Needs compute_params() at the current clock.  Returns tard_unproc
-// (delay_time_sum_unprocessed, :110-122) and leaves obs[0..n_obs) in LDS scratch.
+// ------------------------------------------------------------------ observation
+// SO_FJSSP.py:78-97 state_extract (+ the ratios of update_parameter :156-165), in three parts:
 //
-// The three mean/std pairs are strictly sequential float sums (:86-95).  Their
-// operands go to LDS and every lane walks one of the arrays in order (lane 1:
-// gap_rate, every other lane: finish_rate; then all lanes: machine time_end), so
-// the chains cost one LDS read + one add per element instead of cross-lane traffic,
-// and two chains advance per instruction.
+//   observe_prepare   (every environment's own wave, lane-parallel) integer statistics, the operand rows of the
+//                     three mean / population-std pairs (finish_rate, gap_rate, machine time_end) and a small
+//                     header, all into the wave's LDS slice;
+//   observe_tail      the strictly sequential part: two passes of left-to-right f64 sums over the rows (:86-95),
+//                     the divisions and square roots.  One lane walks one row, so the whole tail of an
+//                     environment occupies 8 lanes (3 chains + the 4 delay ratios) -- and costs a full wave's
+//                     instruction stream all the same.  In step_kernel ONE wave of the workgroup (the walker)
+//                     therefore runs the tails of all four environments of the workgroup side by side (lane =
+//                     8 * slot + role), between workgroup barriers: the stream is issued once instead of four
+//                     times.  Everywhere else (reset, fused rollout, arrival) each wave runs its own tail;
+//   the caller        (emit_state) picks the finished observation up from the LDS scratch row.
+//
+// The tail lanes write their results straight to the observation's final positions (ObsPos), the mean of the
+// machines' time_end -- needed for its deviations, not part of the observation -- to slot 15.
+enum { H_K = 0, H_M, H_TASKS, H_JOBS, H_DELAY_A, H_DELAY_E, H_JOB_A, H_JOB_E, H_DONE, H_N8 };
+
+template <int V>
+struct ObsPos {
+    // finish_rate, gap_rate, time_end: where the mean and the std of each go in the observation vector
+    static constexpr bool so = is_so_v<V>, mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, sf = V == FJSP_VARIANT_SO_SFJSP;
+    static constexpr int ave0 = so ? 2 : (mo ? 1 : (sf ? 2 : 5)), ave1 = so ? 4 : (mo ? 3 : (sf ? 5 : 7)), ave2 = 15;
+    static constexpr int sd0 = so ? 3 : (mo ? 2 : (sf ? 3 : 6)), sd1 = so ? 5 : (mo ? 4 : (sf ? 6 : 8)),
+                         sd2 = so ? 1 : (mo ? 0 : (sf ? 1 : 3));
+    static constexpr int ratio0 = so ? 6 : (mo ? 5 : 11);    // (delay_a, delay_e)/tasks, (job_a, job_e)/jobs; unused slots for SO_SFJSP
+};
+
+template <bool SHARED>
+__device__ __forceinline__ void tail_sync() {
+    if constexpr (SHARED) {
+        // workgroup barrier with LDS-only fences (a plain __syncthreads() also drains the global traffic)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    } else {
+        wave_sync();
+    }
+}
+
+// Integer statistics + operand rows + tail header.  Needs compute_params() at the current clock.  Returns
+// tard_unproc (delay_time_sum_unprocessed, :110-122); frv / grv keep this lane's finish_rate / gap_rate for the
+// deviations of the second pass.
 template <int KC, int V>
-__device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = false) {
+__device__ __forceinline__ long long observe_prepare(W<KC, V> &w, bool stats_only, double (&frv)[KC], double (&grv)[KC]) {
     const int K = w.K, M = w.M;
     bool single_job = true;      // every operation type has exactly one job (10x5, Mk01..10): counts are 0 or 1
 #pragma unroll
@@ -1020,51 +1120,93 @@ __device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = fals
     // a rollout that never hands a state back (rule sweeps read makespan / tardiness / energy only) needs the
     // tardiness of the unfinished jobs for the reward and nothing else of the observation
     if (stats_only) return V == FJSP_VARIANT_SO_SFJSP ? 0 : tard_unproc;
-    // ---- the three mean / population-std pairs (:84-95).  Lane 0 walks finish_rate, lane 1 gap_rate,
-    // lane 2 the machines' time_end (an exact integer sum, so the f64 walk equals sum(int)/M, :384-385);
-    // the squared deviations are formed lane-parallel between the two walks so the second walk is a
-    // pure add chain as well.  Rows are zero padded to a multiple of 8 (+0.0 is an exact identity).
-    const int n8 = (max(K, M) + 7) & ~7;      // (lane 2 walks M machine entries: a shop can have more machines than operation types)
-    // (offset arithmetic, not a select between the pointer fields of `w`: that would pin `w` in scratch)
-    const uint32_t src_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.frL) - fjsp_lds) +
-                             (w.lane == 1 ? (uint32_t)w.KP * 8u : (w.lane == 2 ? (uint32_t)w.KP * 16u : 0u));
-    const double len = w.lane == 2 ? (double)M : (double)K;
-    double frv[KC], grv[KC];                  // with single_job the divisions below are x / 1.0 == x
+    // ---- operand rows, zero padded to KP entries (+0.0 is an exact identity of a running sum from +0.0)
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int tot = w.tot[c];
         const int k = c * kWave + w.lane;
         const bool valid = k < K;
         const double fnum = (double)(tot - w.nun[c]), gnum = (double)w.nun[c] - fluid_q(w, c);
-        if (single_job) { frv[c] = valid ? fnum : 0.0; grv[c] = valid ? gnum : 0.0; }
+        if (single_job) { frv[c] = valid ? fnum : 0.0; grv[c] = valid ? gnum : 0.0; }     // x / 1.0 == x
         else {
             frv[c] = valid ? fnum / (double)tot : 0.0;              // finish_rate class_FJSSP.py:74-76
             grv[c] = valid ? gnum / (double)w.q0[c] : 0.0;          // gap_rate    class_FJSSP.py:66-68
         }
         w.frL[k] = frv[c]; w.grL[k] = grv[c];
+        // lane 2 of the tail walks the machines' time_end: an exact integer sum, so the f64 walk equals
+        // sum(int) / M (:384-385)
         w.tdL[k] = (c == 0 && w.lane < M) ? (double)w.tend_m : 0.0;
     }
-    wave_sync();
-    // one division for the three means (lanes 0..2) and the four delay ratios of :156-165 (lanes 4..7:
-    // (delay_a, delay_e) / task_number, (job_a, job_e) / job_number)
-    const int rnum = w.lane == 4 ? delay_a : (w.lane == 5 ? delay_e : (w.lane == 6 ? job_a : job_e));
-    const int rden = w.lane < 6 ? task_number : job_number;
-    const double csum = lds_chain_sum(src_off, n8);
-    const double ave = (w.lane < 4 ? csum : (double)rnum) / (w.lane < 4 ? len : (double)rden);
-    const double ave_fr = rld(ave, 0), ave_gr = rld(ave, 1), ave_td = rld(ave, 2);
-    const double ratio = w.done ? 0.0 : ave;             // lanes 4..7
-    wave_sync();
+    // ---- header for the tail lanes: one lane-indexed store
+    int hv = 0;
+    hv = wlane(K, H_K, hv); hv = wlane(M, H_M, hv);
+    hv = wlane(task_number, H_TASKS, hv); hv = wlane(job_number, H_JOBS, hv);
+    hv = wlane(delay_a, H_DELAY_A, hv); hv = wlane(delay_e, H_DELAY_E, hv);
+    hv = wlane(job_a, H_JOB_A, hv); hv = wlane(job_e, H_JOB_E, hv);
+    hv = wlane(w.done, H_DONE, hv);
+    hv = wlane((max(K, M) + 7) & ~7, H_N8, hv);   // (a shop can have more machines than operation types)
+    if (w.lane < 16) w.hdrL[w.lane] = hv;
+    return tard_unproc;
+}
+
+// One pass of the tail for up to four environments whose LDS slices start at slot0 + e * stride (e < nslots;
+// nslots == 1: the wave's own slice).  Lane L serves slot (L >> 3) & 3 in role L & 7: roles 0..2 walk the
+// finish_rate / gap_rate / time_end rows, roles 4..7 form the delay ratios of :156-165.  First pass: the row
+// sums become the three means (and the ratios are formed -- one division instruction for all of them); second
+// pass (rows now hold the squared deviations): population standard deviations.
+template <int V, int RING>
+__device__ __forceinline__ void tail_pass(unsigned char *slot0, uint32_t stride, int nslots, int KP, bool second) {
+    const int lane = (int)__lane_id();
+    const int e = (lane >> 3) & 3, r = lane & 7;
+    const bool live = e < nslots;
+    unsigned char *sl = slot0 + (live ? (uint32_t)e * stride : 0u);
+    double *scr = reinterpret_cast<double *>(sl);
+    const int32_t *hdr = reinterpret_cast<const int32_t *>(sl + 16 * 8);
+    const double *row = reinterpret_cast<const double *>(sl + 24 * 8) + (r < 3 ? r * (KP + 2) : 0);
+    // every header word this lane needs, fetched before the walk (the walk is hand-scheduled asm: nothing moves across it)
+    const int n8_l = live ? hdr[H_N8] : 0;
+    const int len_i = hdr[r == 2 ? H_M : H_K];
+    const int rnum = hdr[r >= 4 ? r : H_DELAY_A];                           // roles 4..7: delay_a, delay_e, job_a, job_e
+    const int rden = hdr[r < 6 ? H_TASKS : H_JOBS];
+    const int done = hdr[H_DONE];
+    // the longest row of the (up to four) slots bounds everybody's walk; rows are zero padded to KP
+    int n8 = max(max(rl(n8_l, 0), rl(n8_l, 8)), max(rl(n8_l, 16), rl(n8_l, 24)));
+    n8 = max(n8, 8);
+    const double csum = lds_chain_sum<RING>(row, n8);
+    using P = ObsPos<V>;
+    if (!second) {
+        const double ave = (r < 4 ? csum : (double)rnum) / (r < 4 ? (double)len_i : (double)rden);
+        const double out = (r >= 4 && done) ? 0.0 : ave;                   // the ratios are 0 once the episode is over (:156-165)
+        const int pos = r == 0 ? P::ave0 : (r == 1 ? P::ave1 : (r == 2 ? P::ave2 : P::ratio0 + r - 4));
+        if (live && r != 3) scr[pos] = out;
+    } else {
+        const double sd = sqrt(csum / (double)len_i);
+        const int pos = r == 0 ? P::sd0 : (r == 1 ? P::sd1 : P::sd2);
+        if (live && r < 3) scr[pos] = sd;
+    }
+}
+
+// Second-pass operands: the squared deviations from the means the first pass left in the scratch row
+// (math.pow(d, 2), :86-95), formed lane-parallel by the environment's own wave.
+template <int KC, int V>
+__device__ __forceinline__ void observe_deviations(W<KC, V> &w, const double (&frv)[KC], const double (&grv)[KC]) {
+    using P = ObsPos<V>;
+    const double ave_fr = w.scrL[P::ave0], ave_gr = w.scrL[P::ave1], ave_td = w.scrL[P::ave2];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int k = c * kWave + w.lane;
-        const bool valid = k < K;
-        const double d1 = frv[c] - ave_fr, d2 = grv[c] - ave_gr;                    // math.pow(d, 2)
+        const bool valid = k < w.K;
+        const double d1 = frv[c] - ave_fr, d2 = grv[c] - ave_gr;
         w.frL[k] = valid ? d1 * d1 : 0.0; w.grL[k] = valid ? d2 * d2 : 0.0;
-        if (c == 0) { const double d3 = (double)w.tend_m - ave_td; w.tdL[k] = w.lane < M ? d3 * d3 : 0.0; }
+        if (c == 0) { const double d3 = (double)w.tend_m - ave_td; w.tdL[k] = w.lane < w.M ? d3 * d3 : 0.0; }
     }
-    wave_sync();
-    const double sd = sqrt(lds_chain_sum(src_off, n8) / len);
-    const double cro_ave = ave_fr, cro_std = rld(sd, 0), gap_ave = ave_gr, gap_std = rld(sd, 1), ct_std = rld(sd, 2);
+}
+
+// The rest of the observation once the tail has run: static entries, and for SO_SFJSP / MO_DFJSP the
+// per-machine gap_ave statistics.  Leaves obs[0..n_obs) in the LDS scratch row.
+template <int KC, int V, int RING = 2>
+__device__ __forceinline__ void observe_finish(W<KC, V> &w) {
+    const int M = w.M;
     if (V == FJSP_VARIANT_SO_SFJSP || V == kDyn) {
         // MO_DFJSP_breakdown.py:94-118: [DDT, M, S, ct_std, ratio_idle, cro_ave, cro_std, gap_ave, gap_std, gap_m_ave,
         //                                gap_m_std, dro_a, dro_e, drj_a, drj_e]
@@ -1086,7 +1228,7 @@ __device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = fals
         wave_sync_global();
         double gave_m = 0.0;                       // lane m (< M): gap_ave of machine m
         for (int m0 = 0; m0 < M; m0 += 3) {
-            const double v = gap_ave3<KC, V>(w, m0, m0 + 1 < M ? m0 + 1 : -1, m0 + 2 < M ? m0 + 2 : -1);
+            const double v = gap_ave3<KC, V, RING>(w, m0, m0 + 1 < M ? m0 + 1 : -1, m0 + 2 < M ? m0 + 2 : -1);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (w.lane == m0 + q) gave_m = rld(v, q);
@@ -1094,40 +1236,42 @@ __device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = fals
         // gap_m_ave / gap_m_std over machines in ascending order (:78-80)
         if (w.lane < (uint32_t)w.KP) w.tdL[w.lane] = w.lane < M ? gave_m : 0.0;
         wave_sync();
-        const uint32_t td_off = (uint32_t)(reinterpret_cast<const unsigned char *>(w.tdL) - fjsp_lds);
         const int m8 = (M + 7) & ~7;
-        const double gm_ave = lds_chain_sum(td_off, m8) / (double)M;
+        const double gm_ave = lds_chain_sum<RING>(w.tdL, m8) / (double)M;
         wave_sync();
         { const double d = gave_m - gm_ave; if (w.lane < (uint32_t)w.KP) w.tdL[w.lane] = w.lane < M ? d * d : 0.0; }
         wave_sync();
-        const double gm_std = sqrt(lds_chain_sum(td_off, m8) / (double)M);
-        if (V == kDyn) {
-            wave_sync();
-            if (w.lane == 0) {
-                w.scrL[0] = w.sstate[0]; w.scrL[1] = (double)M; w.scrL[2] = (double)w.n_orders; w.scrL[3] = ct_std;
-                w.scrL[4] = ratio_idle; w.scrL[5] = cro_ave; w.scrL[6] = cro_std; w.scrL[7] = gap_ave; w.scrL[8] = gap_std;
-                w.scrL[9] = gm_ave; w.scrL[10] = gm_std;
-            }
-            if (w.lane >= 4 && w.lane < 8) w.scrL[7 + w.lane] = ratio;                    // :176-185
-            wave_sync();
-            return tard_unproc;
-        }
+        const double gm_std = sqrt(lds_chain_sum<RING>(w.tdL, m8) / (double)M);
         if (w.lane == 0) {
-            w.scrL[0] = m_idle_ratio; w.scrL[1] = ct_std; w.scrL[2] = cro_ave; w.scrL[3] = cro_std; w.scrL[4] = ratio_idle;
-            w.scrL[5] = gap_ave; w.scrL[6] = gap_std; w.scrL[7] = gm_ave; w.scrL[8] = gm_std;
+            if (V == kDyn) {
+                w.scrL[0] = w.sstate[0]; w.scrL[1] = (double)M; w.scrL[2] = (double)w.n_orders; w.scrL[4] = ratio_idle;
+                w.scrL[9] = gm_ave; w.scrL[10] = gm_std;
+            } else {
+                w.scrL[0] = m_idle_ratio; w.scrL[4] = ratio_idle; w.scrL[7] = gm_ave; w.scrL[8] = gm_std;
+            }
         }
-        wave_sync();
-        return 0;          // this subclass never calls update_parameter: delay_time_sum_unprocessed stays 0
+    } else if (is_so_v<V>) {
+        if (w.lane == 0) w.scrL[0] = (double)M;
     }
-    const int o0 = is_so_v<V> ? 1 : 0;
-    if (w.lane == 0) {
-        if (is_so_v<V>) w.scrL[0] = (double)M;
-        w.scrL[o0] = ct_std; w.scrL[o0 + 1] = cro_ave; w.scrL[o0 + 2] = cro_std; w.scrL[o0 + 3] = gap_ave;
-        w.scrL[o0 + 4] = gap_std;
-    }
-    if (w.lane >= 4 && w.lane < 8) w.scrL[o0 + 1 + w.lane] = ratio;
     wave_sync();
-    return tard_unproc;
+}
+
+// The whole observation by the environment's own wave (reset, fused rollout, arrival).  Returns tard_unproc.
+template <int KC, int V, int RING = 2>
+__device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = false) {
+    double frv[KC], grv[KC];
+    const long long tard_unproc = observe_prepare<KC, V>(w, stats_only, frv, grv);
+    if (stats_only) return tard_unproc;
+    const uint32_t stride = 0;
+    wave_sync();
+    tail_pass<V, RING>(reinterpret_cast<unsigned char *>(w.scrL), stride, 1, w.KP, false);
+    wave_sync();
+    observe_deviations<KC, V>(w, frv, grv);
+    wave_sync();
+    tail_pass<V, RING>(reinterpret_cast<unsigned char *>(w.scrL), stride, 1, w.KP, true);
+    wave_sync();
+    observe_finish<KC, V, RING>(w);
+    return V == FJSP_VARIANT_SO_SFJSP ? 0 : tard_unproc;      // SO_SFJSP never calls update_parameter: delay_time_sum_unprocessed stays 0
 }
 
 // state = [static, v(t), v(t) - v(t-1)]  (SO_FJSSP.py:71-72,257-258); updates obs_prev.
@@ -1155,7 +1299,7 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
     w.busy = 0; w.completion = 0; w.completion_last = 0;
     w.tard_done = 0; w.delay_sum = 0;
     w.tend_m = 0; w.mjob_m = -1;
-    w.t_arr = 0; w.next_order = 1; w.pending = 0;
+    w.t_arr = 0; w.next_order = 1; w.pending = 0; w.obs_stale = 0;
     w.energy = 0; w.energy_last = 0; w.tlast_m = -1;
     if (is_mord_v<V>) {
         // per-environment copy of the reset-time fluid tables (they change at every later arrival)
@@ -1203,63 +1347,47 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
     emit_state<KC, V>(w, state_out, true);
 }
 
-// One environment step.  compute_params() must be current on entry and is
-// current again on exit (the fused kernel carries it across steps).
-template <int KC, int V>
-__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs = true);
-
-template <int KC, int V>
-__device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a0, int a1, const double *mo,
-                                           double *state_out, int *k_out, int *m_out, bool need_obs = true) {
+// First half of step() (SO_FJSSP.py:168-250): rule pair -> (operation type, machine), dispatch, event loop.
+// compute_params() must be current on entry.  Returns true when the step goes on to its second half now
+// (false: an error status was set, or -- multi-order batches -- the env parked at an order arrival).
+template <int KC, int V, int RING = 2>
+__device__ __forceinline__ bool env_step_decide(W<KC, V> &w, const DevBatch *b, int a0, int a1, int *k_out, int *m_out) {
     const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
+    *k_out = -1; *m_out = -1;
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
-        if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }   // IndexError
+        if (a0 >= 18) { w.status |= FJSP_ST_BAD_TASK_RULE; return false; }   // IndexError
         a1 = a0 % 3; a0 = a0 / 3;
     } else if (is_sf) {              // SO_SFJSP.py:25,87-88
-        if (a0 >= 20) { w.status |= FJSP_ST_BAD_TASK_RULE; *k_out = -1; *m_out = -1; return 0.0; }
+        if (a0 >= 20) { w.status |= FJSP_ST_BAD_TASK_RULE; return false; }
         a1 = a0 % 5; a0 = a0 / 5;
     }
     const uint32_t idle = ~w.busy & w.mmask;
     const int k_sel = task_select<KC, V>(w, a0, idle);
     STAMP(w, 2);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 7
-    w.rng_calls += (uint32_t)k_sel; *k_out = k_sel; *m_out = -1; return 0.0;      // diagnostic: stop after task_select
+    w.rng_calls += (uint32_t)k_sel; *k_out = k_sel; return false;      // diagnostic: stop after task_select
 #endif
     int pm = 0, en_sel = 0;
     double un_sel = 0.0;
-    const int m_sel = k_sel >= 0 ? machine_select<KC, V>(w, a1, k_sel, idle, &pm, &un_sel, &en_sel) : -1;
+    const int m_sel = k_sel >= 0 ? machine_select<KC, V, RING>(w, a1, k_sel, idle, &pm, &un_sel, &en_sel) : -1;
     STAMP(w, 3);
     *k_out = k_sel; *m_out = m_sel;
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 8
-    w.rng_calls += (uint32_t)(k_sel + m_sel + pm); return un_sel;                 // diagnostic: stop after machine_select
+    w.rng_calls += (uint32_t)(k_sel + m_sel + pm) + (uint32_t)un_sel; return false;   // diagnostic: stop after machine_select
 #endif
-    if (k_sel < 0 || m_sel < 0) return 0.0;         // status carries the MyError / undefined-behaviour bit
+    if (k_sel < 0 || m_sel < 0) return false;       // status carries the MyError / undefined-behaviour bit
     dispatch_and_advance<KC, V>(w, b, k_sel, m_sel, pm, un_sel, en_sel);
     STAMP(w, 4);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 9
-    return 0.0;                                                                   // diagnostic: stop after dispatch_and_advance
+    return false;                                                                 // diagnostic: stop after dispatch_and_advance
 #endif
-    if (is_mord_v<V> && w.pending) return 0.0;        // an order arrived: the step is finished by arrival_kernel
-    return env_step_finish<KC, V>(w, mo, state_out, need_obs);
+    return !(is_mord_v<V> && w.pending);            // an order arrived: the step is finished by arrival_kernel
 }
 
-// Second half of step() (SO_FJSSP.py:252-265): observation, reward, bookkeeping.
+// Reward and bookkeeping of step() (SO_FJSSP.py:259-265) once the observation is out.
 template <int KC, int V>
-__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs) {
+__device__ __forceinline__ double step_reward(W<KC, V> &w, const double *mo, long long tard_unproc) {
     const bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, is_sf = V == FJSP_VARIANT_SO_SFJSP;
-    w.step_count++;                                                          // :252
-    compute_params<KC, V>(w);
-    STAMP(w, 5);
-#if defined(FJSP_ABLATE) && FJSP_ABLATE == 2
-    const long long tard_unproc = 0;            // diagnostic: no observation
-#elif defined(FJSP_ABLATE) && FJSP_ABLATE == 1
-    const long long tard_unproc = observe<KC, V>(w);   // diagnostic: observation computed, not emitted
-#else
-    const long long tard_unproc = observe<KC, V>(w, !need_obs);                // :256
-    STAMP(w, 6);
-    if (need_obs) emit_state<KC, V>(w, state_out, false);
-    STAMP(w, 7);
-#endif
     const long long delay_new = w.tard_done + tard_unproc;                   // :259
     const long long delta = delay_new - w.delay_sum;
     const int dc = w.completion_last - w.completion;
@@ -1289,6 +1417,40 @@ __device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo,
     if (w0 == 1.0) return (double)dc;
     w.status |= FJSP_ST_BAD_TASK_RULE;                                       // MyError :244
     return 0.0;
+}
+
+// Second half of step() (SO_FJSSP.py:252-265) by the environment's own wave: observation, reward, bookkeeping.
+// A step that hands no state back skips the observation and marks the kept v(t-1) stale (obs_refresh).
+template <int KC, int V, int RING = 2>
+__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs = true) {
+    w.step_count++;                                                          // :252
+    compute_params<KC, V>(w);
+    STAMP(w, 5);
+    const long long tard_unproc = observe<KC, V, RING>(w, !need_obs);         // :256
+    STAMP(w, 6);
+    if (need_obs) emit_state<KC, V>(w, state_out, false);
+    else w.obs_stale = 1;
+    STAMP(w, 7);
+    return step_reward<KC, V>(w, mo, tard_unproc);
+}
+
+// v(t-1) of the state vector (SO_FJSSP.py:257-258) is the observation of the environment as the previous
+// step left it, i.e. as this step finds it.  Steps that hand no state back do not keep it current; the first
+// step that wants a state again rebuilds it here, before anything is dispatched.
+template <int KC, int V>
+__device__ __forceinline__ void obs_refresh(W<KC, V> &w) {
+    observe<KC, V>(w);
+    w.obs_prev_l = w.lane < w.n_obs ? w.scrL[w.lane] : 0.0;
+    w.obs_stale = 0;
+    wave_sync();
+}
+
+template <int KC, int V, int RING = 2>
+__device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a0, int a1, const double *mo,
+                                           double *state_out, int *k_out, int *m_out, bool need_obs = true) {
+    if (need_obs && w.obs_stale) obs_refresh<KC, V>(w);
+    if (!env_step_decide<KC, V, RING>(w, b, a0, a1, k_out, m_out)) return 0.0;
+    return env_step_finish<KC, V, RING>(w, mo, state_out, need_obs);
 }
 
 // ------------------------------------------------------------------------ kernels
@@ -1347,38 +1509,51 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
     store_dynamic<KC, V>(w, false);
 }
 
+// One step of every environment.  Single-order variants share the observation tail inside the workgroup
+// (observe_tail above): every live wave of a workgroup passes the same four barriers, whatever happened to its
+// environment (finished episode, invalid rule), so nothing below returns between the first barrier and the last.
 template <int KC, int V>
 // (four chunks of per-lane operation state do not fit 128 VGPRs: K > 128 runs at half the occupancy instead of spilling)
 __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
                                                       double *state_out, double *reward_out, uint8_t *done_out,
                                                       int16_t *trace_km) {
+    constexpr bool SHARED = FJSP_SHARED_TAIL && !is_mord_v<V>;
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
-    const int env = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (env >= b.N) return;
+    const int env_raw = blockIdx.x * (blockDim.x >> 6) + wave;
+    // the waves past the last environment of a partial workgroup address the last environment until their loads are
+    // out and leave then: no kernel argument has to arrive before the state loads can be issued
+    const int env = min(env_raw, b.N - 1);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 5
     return;                                     // diagnostic: launch overhead only
 #endif
     W<KC, V> w;
     STAMP_BEGIN(w);
-    const int a0 = actions[(size_t)env * 2], a1 = actions[(size_t)env * 2 + 1];
-    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
+    // the action pair is wave-uniform: one scalar load when the tensor is 4-byte aligned (it is, unless a caller
+    // slices an odd number of environments off a larger tensor)
+    int a0, a1;
+    if ((reinterpret_cast<uintptr_t>(actions) & 3u) == 0) {
+        const uint32_t word = reinterpret_cast<const uint32_t *>(actions)[env >> 1] >> ((env & 1) * 16);
+        a0 = (int)(word & 0xFFu); a1 = (int)((word >> 8) & 0xFFu);
+    } else {
+        a0 = uni((int)actions[(size_t)env * 2]); a1 = uni((int)actions[(size_t)env * 2 + 1]);
+    }
+    const uint32_t lds_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_stride, false, true);
+    if (env_raw >= b.N) return;                       // (a finished wave no longer counts at the workgroup's barriers)
     STAMP(w, 0);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 4
     store_dynamic<KC, V>(w, false);                // diagnostic: state in / state out only
     return;
 #endif
+    const bool need_obs = state_out != nullptr;
+    bool go = true;                  // this wave's environment takes a step in this launch
     if (w.done) {
         if (autoreset != 1) {        // 0: flag the misuse; 2: idle silently (non-fused rollout fallback)
             if (autoreset == 0) w.status |= FJSP_ST_STEP_AFTER_DONE;
-            if (w.lane == 0) {
-                env_ptr<EnvScalars>(b, env, 0)->status = w.status;
-                if (reward_out) reward_out[env] = 0.0;
-                if (done_out) done_out[env] = 1;
-                if (trace_km) { trace_km[(size_t)env * 2] = -1; trace_km[(size_t)env * 2 + 1] = -1; }
-            }
-            return;
+            go = false;
+        } else {
+            init_episode<KC, V>(w, &b, nullptr, true);
         }
-        init_episode<KC, V>(w, &b, nullptr, true);
     } else {
         compute_params<KC, V>(w);
     }
@@ -1387,26 +1562,78 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
     store_dynamic<KC, V>(w, false);                // diagnostic: + compute_params
     return;
 #endif
-    int k_sel, m_sel;
-    const double reward = env_step<KC, V>(w, &b, uni(a0), uni(a1), mo ? mo + (size_t)env * 4 : nullptr, state_out, &k_sel, &m_sel);
-    if (is_mord_v<V> && w.pending) {
-        // an order arrived inside this step: park the env for the host LP service (fjsp_env.hip), which
-        // finishes the step with arrival_kernel; the outputs of this env are written there
-        if (w.lane == 0) {
-            int16_t *stash = reinterpret_cast<int16_t *>(w.er + b.L.e_lpq) + 2 * b.KP;
-            stash[0] = (int16_t)k_sel; stash[1] = (int16_t)m_sel;
+    int k_sel = -1, m_sel = -1;
+    double reward = 0.0;
+    const double *mo_e = mo ? mo + (size_t)env * 4 : nullptr;
+    if constexpr (!SHARED) {
+        if (go) reward = env_step<KC, V, 8>(w, &b, a0, a1, mo_e, state_out, &k_sel, &m_sel, need_obs);
+        if (go && w.pending) {
+            // an order arrived inside this step: park the env for the host LP service (fjsp_env.hip), which
+            // finishes the step with arrival_kernel; the outputs of this env are written there
+            if (w.lane == 0) {
+                int16_t *stash = reinterpret_cast<int16_t *>(w.er + b.L.e_lpq) + 2 * b.KP;
+                stash[0] = (int16_t)k_sel; stash[1] = (int16_t)m_sel;
+            }
+            // take a slot of the service's staging area and leave the LP inputs there: the host fetches the
+            // inputs of all parked envs with one copy
+            uint32_t slot = 0;
+            if (w.lane == 0) { slot = atomicAdd(b.pending_count, 1u); b.pending_count[1 + slot] = (uint32_t)env; }
+            slot = uniu(slot);
+            wave_sync_global();
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(w.er + b.L.e_lpq);     // u16[2][KP] as KP words
+            uint32_t *dst = reinterpret_cast<uint32_t *>(b.lp_in + (size_t)slot * 2 * b.KP);
+            for (int i = w.lane; i < b.KP; i += kWave) dst[i] = src[i];
+            store_dynamic<KC, V>(w, false);
+            return;
         }
-        // take a slot of the service's staging area and leave the LP inputs there: the host fetches the
-        // inputs of all parked envs with one copy
-        uint32_t slot = 0;
-        if (w.lane == 0) { slot = atomicAdd(b.pending_count, 1u); b.pending_count[1 + slot] = (uint32_t)env; }
-        slot = uniu(slot);
-        wave_sync_global();
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(w.er + b.L.e_lpq);     // u16[2][KP] as KP words
-        uint32_t *dst = reinterpret_cast<uint32_t *>(b.lp_in + (size_t)slot * 2 * b.KP);
-        for (int i = w.lane; i < b.KP; i += kWave) dst[i] = src[i];
+    } else {
+        if (go && need_obs && w.obs_stale) obs_refresh<KC, V>(w);
+        if (go) go = env_step_decide<KC, V, 8>(w, &b, a0, a1, &k_sel, &m_sel);
+#if defined(FJSP_ABLATE) && (FJSP_ABLATE == 7 || FJSP_ABLATE == 8 || FJSP_ABLATE == 9)
         store_dynamic<KC, V>(w, false);
         return;
+#endif
+        double frv[KC], grv[KC];
+        long long tard_unproc = 0;
+        if (go) {
+            w.step_count++;                                                  // SO_FJSSP.py:252
+            compute_params<KC, V>(w);
+            STAMP(w, 5);
+#if !(defined(FJSP_ABLATE) && FJSP_ABLATE == 2)
+            tard_unproc = observe_prepare<KC, V>(w, !need_obs, frv, grv);
+#endif
+            STAMP(w, 6);
+        }
+#if !(defined(FJSP_ABLATE) && FJSP_ABLATE == 2)
+        if (need_obs) {              // (uniform over the grid: a kernel argument)
+            // the walker runs the sequential tail of every environment of the workgroup; slots whose wave has
+            // nothing to observe (finished episode, error) announce an empty row
+            const int nslots = min(4, b.N - (int)blockIdx.x * 4);
+            const int walker = min((int)(blockIdx.x & 3u), nslots - 1);
+            if (!go && w.lane == 0) w.hdrL[H_N8] = 0;
+            tail_sync<true>();
+            STAMP(w, 7);
+            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, b.KP, false);
+            tail_sync<true>();
+            STAMP(w, 8);
+            if (go) observe_deviations<KC, V>(w, frv, grv);
+            tail_sync<true>();
+            STAMP(w, 9);
+            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, b.KP, true);
+            tail_sync<true>();
+            STAMP(w, 10);
+            if (go) {
+                observe_finish<KC, V, 8>(w);
+#if !(defined(FJSP_ABLATE) && FJSP_ABLATE == 1)
+                emit_state<KC, V>(w, state_out, false);
+#endif
+                STAMP(w, 11);
+            }
+        } else if (go) {
+            w.obs_stale = 1;
+        }
+#endif
+        if (go) reward = step_reward<KC, V>(w, mo_e, V == FJSP_VARIANT_SO_SFJSP ? 0 : tard_unproc);
     }
     if (w.lane == 0) {
         if (reward_out) reward_out[env] = reward;
@@ -1414,7 +1641,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
         if (trace_km) { trace_km[(size_t)env * 2] = (int16_t)k_sel; trace_km[(size_t)env * 2 + 1] = (int16_t)m_sel; }
     }
     store_dynamic<KC, V>(w, false);
-    STAMP(w, 8);
+    STAMP(w, 12);
     STAMP_FLUSH(w);
 }
 
