@@ -46,6 +46,7 @@ SIGNATURES = {
     "fjsp_env_device": (C.c_int, [_vp]),
     "fjsp_env_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fjsp_env_step": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "fjsp_env_step_traced": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "fjsp_env_rollout": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "fjsp_env_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fjsp_env_machine_time_end": (C.c_int, [_vp, _vp, _i32, _vp]),

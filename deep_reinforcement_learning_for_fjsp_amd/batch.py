@@ -25,14 +25,72 @@ ST_STEP_AFTER_DONE = 4
 ST_NO_EVENT = 8
 
 
+ENV_SEED_STRIDE = 1000003          # env e draws random.choice from the stream seeded rng_seed + e * ENV_SEED_STRIDE
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _splitmix64(z):
+    """numpy uint64 vector form of the splitmix64 finaliser the kernels use (fjsp_kernels.hip)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def global_actions(seed, first_env, n_envs, T, n_task_rules, n_machine_rules):
+    """uint8[T, n_envs, 2] random rule pairs that are a pure function of (seed, GLOBAL env id, step): a shard
+    [first_env, first_env + n_envs) of a larger batch draws exactly what the unsharded batch draws for those
+    environments, whatever the number of GPUs."""
+    import numpy as np
+    g = (np.arange(n_envs, dtype=np.uint64) + np.uint64(first_env))[None, :]
+    t = np.arange(T, dtype=np.uint64)[:, None]
+    with np.errstate(over="ignore"):
+        u = _splitmix64(_splitmix64(np.uint64(seed) + g * np.uint64(0x632BE59BD9B4E019)) + t)
+    a0 = ((u >> np.uint64(40)) % np.uint64(n_task_rules)).astype(np.uint8)
+    a1 = ((u >> np.uint64(8)) % np.uint64(max(n_machine_rules, 1))).astype(np.uint8)
+    return np.ascontiguousarray(np.stack([a0, a1], 2))
+
+
+def _as_input(name, t, shape, dtype, device):
+    """An INPUT tensor of the C ABI: converted to the dtype / device / layout the kernels read, shape enforced
+    (the library takes raw pointers: a wrong extent would be an out-of-bounds device access, not an exception)."""
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    if t.dtype != dtype or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=dtype).contiguous()
+    return t
+
+
+def _check_output(name, t, shape, dtype, device):
+    """An OUTPUT tensor of the C ABI is written in place: it cannot be converted, only checked."""
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        raise ValueError("%s must be a torch tensor" % name)
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous %s tensor of shape %s on %s, got %s %s on %s%s"
+                         % (name, dtype, tuple(shape), device, t.dtype, tuple(t.shape), t.device,
+                            "" if t.is_contiguous() else " (not contiguous)"))
+    return t
 
 
 class EnvBatch(object):
     """fjsp_env handle + the device tensors it writes into."""
 
-    def __init__(self, instances, n_envs, first=0, n_inst=None, variant=VARIANT_SO_FJSSP, device=0, rng_seed=0):
+    def __init__(self, instances, n_envs, first=0, n_inst=None, variant=VARIANT_SO_FJSSP, device=0, rng_seed=0,
+                 first_env=0):
+        """first_env: GLOBAL id of this batch's environment 0 when the batch is one shard of a larger job (one
+        rank of `bench.py --gpus N` / examples/train_ppo.py).  The random.choice stream of an environment is a
+        function of its global id, so the traces of a sharded job equal the unsharded job's bit for bit."""
         if not torch.cuda.is_available():
             raise RuntimeError("EnvBatch needs an MI355X: the environment kernels have no CPU path")
         self._lib = _capi.lib()
@@ -41,8 +99,11 @@ class EnvBatch(object):
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         self._h = C.c_void_p()
+        self.first_env = int(first_env)
+        # the kernels seed env e (local) with seed + e * ENV_SEED_STRIDE: shift the base by the shard's offset
+        lib_seed = (int(rng_seed) + self.first_env * ENV_SEED_STRIDE) & (2 ** 64 - 1)
         check(self._lib.fjsp_env_create(instances.handle, int(first), int(n_inst), int(n_envs), int(variant),
-                                        self.device_index, int(rng_seed) & (2 ** 64 - 1), C.byref(self._h)))
+                                        self.device_index, lib_seed, C.byref(self._h)))
         self.N = int(n_envs)
         self.n_inst = int(n_inst)
         self.first = int(first)
@@ -65,15 +126,17 @@ class EnvBatch(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def env_seed(self, e):
-        """random.choice stream seed of env e (matches fjsp_kernels.hip bind())."""
-        return (self.rng_seed + e * 1000003) & (2 ** 64 - 1)
+        """random.choice stream seed of (local) env e (matches open_env() in fjsp_kernels.hip)."""
+        return (self.rng_seed + (self.first_env + e) * ENV_SEED_STRIDE) & (2 ** 64 - 1)
 
     # -- reset / step ------------------------------------------------------------
     def reset(self, mask=None, out=None):
         """reset(): SO_FJSSP.py:51-76 for every env (or those with mask != 0). Returns f64[N, S]."""
-        out = self.state if out is None else out
+        out = self.state if out is None else _check_output("out", out, (self.N, self.state_size), torch.float64, self.device)
         if mask is not None:
-            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if torch.is_tensor(mask) and mask.dtype == torch.bool:
+                mask = mask.to(torch.uint8)
+            mask = _as_input("mask", mask, (self.N,), torch.uint8, self.device)
         check(self._lib.fjsp_env_reset(self._h, _ptr(mask), _ptr(out), self._stream()))
         if mask is None:
             self.done.zero_()
@@ -81,25 +144,42 @@ class EnvBatch(object):
             self.done.masked_fill_(mask.bool(), 0)
         return out
 
-    def step(self, actions, autoreset=False, state_out=None, reward_out=None, done_out=None, mo=None):
+    def step(self, actions, autoreset=False, state_out=None, reward_out=None, done_out=None, mo=None, state=True,
+             trace_out=None):
         """step(action): SO_FJSSP.py:168-265.  actions: uint8[N, 2] device tensor.  For the MO variant
         actions[:, 0] is the flat action and `mo` (f64[N, 4] = w0, w1, completion, tardiness; <= 0 = None)
         carries step()'s extra arguments (MO_FJSSP_discretes.py:88); for MO_DFJSP `mo` is f64[N, 4] =
-        reward_policy, completion, tardiness, energy_consumption (MO_DFJSP_breakdown.py:189)."""
-        if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
-            actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
-        state_out = self.state if state_out is None else state_out
-        reward_out = self.reward if reward_out is None else reward_out
-        done_out = self.done if done_out is None else done_out
-        check(self._lib.fjsp_env_step(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, _ptr(state_out),
-                                      _ptr(reward_out), _ptr(done_out), self._stream()))
+        reward_policy, completion, tardiness, energy_consumption (MO_DFJSP_breakdown.py:189).
+        state=False: no state is returned and the kernel skips the observation (rule policies that never look at
+        it); later calls that do return a state are unaffected (the library rebuilds v(t-1) first).
+        trace_out: int16[N, 2] tensor that receives the chosen (operation type k, machine m) of every env."""
+        actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
+        mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
+        state_out = self.state if state_out is None else _check_output("state_out", state_out, (self.N, self.state_size),
+                                                                       torch.float64, self.device)
+        reward_out = self.reward if reward_out is None else _check_output("reward_out", reward_out, (self.N,),
+                                                                          torch.float64, self.device)
+        done_out = self.done if done_out is None else _check_output("done_out", done_out, (self.N,), torch.uint8, self.device)
+        if not state:
+            state_out = None
+        if trace_out is not None:
+            _check_output("trace_out", trace_out, (self.N, 2), torch.int16, self.device)
+            check(self._lib.fjsp_env_step_traced(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, _ptr(state_out),
+                                                 _ptr(reward_out), _ptr(done_out), _ptr(trace_out), self._stream()))
+        else:
+            check(self._lib.fjsp_env_step(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, _ptr(state_out),
+                                          _ptr(reward_out), _ptr(done_out), self._stream()))
         return state_out, reward_out, done_out
 
     def rollout(self, actions, trace=True, rewards=True, mo=None, state=True):
         """T fused steps in one launch. actions: uint8[T, N, 2]. Returns (trace_km i16[T,N,2], reward f64[T,N], state).
-        state=False: no final state (the fused kernel then skips the observation; reset before stepping again)."""
-        if actions.dtype != torch.uint8 or not actions.is_contiguous() or actions.device != self.device:
-            actions = actions.to(device=self.device, dtype=torch.uint8).contiguous()
+        state=False: no final state (the fused kernel then skips the observation)."""
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(actions)
+        if actions.dim() != 3:
+            raise ValueError("actions must have shape (T, %d, 2), got %s" % (self.N, tuple(actions.shape)))
+        actions = _as_input("actions", actions, (actions.shape[0], self.N, 2), torch.uint8, self.device)
+        mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
         T = actions.shape[0]
         tr = torch.full((T, self.N, 2), -1, dtype=torch.int16, device=self.device) if trace else None
         rw = torch.zeros(T, self.N, dtype=torch.float64, device=self.device) if rewards else None

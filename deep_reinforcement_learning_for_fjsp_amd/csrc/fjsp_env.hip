@@ -515,15 +515,20 @@ int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *st
     return FJSP_OK;
 }
 
-int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
-                  double *d_reward, uint8_t *d_done, void *stream) {
+int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
+                         double *d_reward, uint8_t *d_done, int16_t *d_trace_km, void *stream) {
     if (!e || !d_actions) { set_error("fjsp_env_step: null argument"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
-    if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, (hipStream_t)stream) != 0) {
+    if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, d_trace_km, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
     }
-    if (e->b.mord) return service_arrivals(e, d_mo, d_state, d_reward, d_done, nullptr, (hipStream_t)stream);
+    if (e->b.mord) return service_arrivals(e, d_mo, d_state, d_reward, d_done, d_trace_km, (hipStream_t)stream);
     return FJSP_OK;
+}
+
+int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
+                  double *d_reward, uint8_t *d_done, void *stream) {
+    return fjsp_env_step_traced(e, d_actions, d_mo, autoreset, d_state, d_reward, d_done, nullptr, stream);
 }
 
 int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t T, int16_t *d_trace_km,

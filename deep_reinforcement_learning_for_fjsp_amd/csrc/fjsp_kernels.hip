@@ -1428,7 +1428,7 @@ __device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo,
     STAMP(w, 5);
     const long long tard_unproc = observe<KC, V, RING>(w, !need_obs);         // :256
     STAMP(w, 6);
-    if (need_obs) emit_state<KC, V>(w, state_out, false);
+    if (need_obs) { emit_state<KC, V>(w, state_out, false); w.obs_stale = 0; }
     else w.obs_stale = 1;
     STAMP(w, 7);
     return step_reward<KC, V>(w, mo, tard_unproc);

@@ -40,11 +40,11 @@ class BatchedSOFJSSP(object):
     state_size = 20
     variant = VARIANT_SO_FJSSP          # (environments/SO_DFJSP.py subclasses with its own variant)
 
-    def __init__(self, instance_set, n_envs=None, first=0, n_inst=None, device=0, rng_seed=0):
+    def __init__(self, instance_set, n_envs=None, first=0, n_inst=None, device=0, rng_seed=0, first_env=0):
         n_inst = len(instance_set) - first if n_inst is None else n_inst
         n_envs = n_inst if n_envs is None else n_envs
         self.batch = EnvBatch(instance_set, n_envs, first=first, n_inst=n_inst, variant=self.variant,
-                              device=device, rng_seed=rng_seed)
+                              device=device, rng_seed=rng_seed, first_env=first_env)
         self.N = self.batch.N
         self.device = self.batch.device
 

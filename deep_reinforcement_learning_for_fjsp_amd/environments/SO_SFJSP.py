@@ -21,11 +21,11 @@ class BatchedSOSFJSP(object):
     action_types = "DISCRETE"
     state_size = 18
 
-    def __init__(self, instance_set, n_envs=None, first=0, n_inst=None, device=0, rng_seed=0):
+    def __init__(self, instance_set, n_envs=None, first=0, n_inst=None, device=0, rng_seed=0, first_env=0):
         n_inst = len(instance_set) - first if n_inst is None else n_inst
         n_envs = n_inst if n_envs is None else n_envs
         self.batch = EnvBatch(instance_set, n_envs, first=first, n_inst=n_inst, variant=VARIANT_SO_SFJSP,
-                              device=device, rng_seed=rng_seed)
+                              device=device, rng_seed=rng_seed, first_env=first_env)
         self.N, self.device = self.batch.N, self.batch.device
         self._act = torch.zeros(self.N, 2, dtype=torch.uint8, device=self.device)
 

@@ -33,7 +33,7 @@ def main():
     torch.cuda.set_device(local)
     N = args.envs_per_gpu
     insts = fi.InstanceSet(N).generate_range(1000 + rank * N, fi.bench_10x5_params()).solve_fluid()
-    env = BatchedSOFJSSP(insts, device=local, rng_seed=7 + rank * N)
+    env = BatchedSOFJSSP(insts, device=local, rng_seed=7, first_env=rank * N)     # streams follow the GLOBAL env id
     torch.manual_seed(1234 + rank)
     agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=not args.eager, fused_sampling=not args.eager)
     agent.run_one_policy_network()          # warm-up round (allocations, kernel caches)

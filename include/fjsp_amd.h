@@ -169,11 +169,22 @@ int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *st
  * completion, tardiness, energy_consumption (MO_DFJSP_breakdown.py:189,430-447;
  * NULL = policy 1; any other policy value sets FJSP_ST_BAD_TASK_RULE like the
  * reference's MyError).  Outputs (all nullable): d_state f64[N][S],
- * d_reward f64[N], d_done u8[N].  Envs already done are left untouched and get
+ * d_reward f64[N], d_done u8[N].  With d_state == NULL the step skips the
+ * observation (state_extract, SO_FJSSP.py:78-97: a third of a step's work) -- for
+ * callers that pick rules without looking at the state; the environment notes
+ * that its remembered v(t-1) is stale and the next call that does return a state
+ * rebuilds it first, so states stay identical to the reference's whatever the
+ * mix of calls.  Envs already done are left untouched and get
  * FJSP_ST_STEP_AFTER_DONE unless autoreset != 0, in which case a done env is
  * reset first and the step applies to the fresh episode. */
 int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset,
                   double *d_state, double *d_reward, uint8_t *d_done, void *stream);
+/* The same step, also reporting what the rule pair resolved to: d_trace_km
+ * i16[N][2] (nullable) = the operation type index k (kind_task_tuple order) and
+ * the machine m that task_select / machine_select chose (SO_FJSSP.py:173-174),
+ * -1 / -1 for an env that did not step. */
+int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset,
+                         double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace_km, void *stream);
 
 /* T fused steps in ONE launch (rule-sweep harnesses, MO_DFJSP.py:481-518 style):
  * d_actions u8[T][N][2]; d_mo as in fjsp_env_step (constant over the T steps);
@@ -181,8 +192,8 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
  * Trace outputs (nullable): d_trace_km i16[T][N][2] = chosen (k, m) or -1,
  * d_reward f64[T][N], d_state_last f64[N][S].  With d_state_last == NULL the
  * fused kernel skips the observation altogether (rule sweeps read makespan /
- * tardiness / energy only); the envs must then be reset before the next call
- * that returns a state (the remembered v(t-1) is stale). */
+ * tardiness / energy only); as in fjsp_env_step the next call that returns a
+ * state rebuilds the remembered v(t-1) first. */
 int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t T, int16_t *d_trace_km,
                      double *d_reward, double *d_state_last, void *stream);
 

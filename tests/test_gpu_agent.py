@@ -116,6 +116,38 @@ def test_batched_ppo_rounds_run_on_the_hip_environment(torch_gpu, use_graph, fus
     assert agent.episode_number == 3 and agent.global_step_number > 0
 
 
+def test_config3_full_size_ppo_round_on_4096_envs(torch_gpu):
+    """BASELINE configs[2] at its full size: 4096 parallel 10x5 SO_FJSSP envs, actor/critic 2x128, the rollout
+    replayed from a captured HIP graph with the fused sampler (the shipped configuration of examples/train_ppo.py),
+    two learning rounds.  Same invariants as the miniature above, on every one of the 4096 environments."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedSOFJSSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import PPO
+    N = 4096
+    s = fi.InstanceSet(N).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
+    env = BatchedSOFJSSP(s, rng_seed=3)
+    torch.manual_seed(0)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=True, fused_sampling=True)
+    K = np.array([s.dims(i)["K"] for i in range(N)])
+    before = [p.detach().clone() for p in agent.learner.actor_new.parameters()] if hasattr(agent, "learner") else None
+    for rnd in range(2):
+        tard, mk, (c_loss, a_loss) = agent.run_one_policy_network()
+        assert np.isfinite(tard) and np.isfinite(mk) and np.isfinite(c_loss) and np.isfinite(a_loss)
+        r = env.read()
+        # (only the "stepped after done" bit may be set: the vector loop runs max_steps launches for every env)
+        assert bool((r["done"] == 1).all()) and int(((r["status"] & ~4) != 0).sum()) == 0
+        assert np.array_equal(r["step_count"].cpu().numpy(), K)
+        n = len(agent.memory)
+        valid = agent.memory.valid[:n]
+        assert np.array_equal(valid.sum(0).cpu().numpy().astype(np.int64), K)    # one valid row per operation
+        tot = (agent.memory.rewards[:n].double() * valid.double()).sum(0)
+        assert torch.equal(-tot.long(), r["delay_time_sum"])                     # rewards telescope to -tardiness
+    assert agent.global_step_number == 2 * int(K.sum())
+    if before is not None:
+        assert any(not torch.equal(b, p) for b, p in zip(before, agent.learner.actor_new.parameters()))
+
+
 def test_multi_policy_ppo_on_mo_discretes(torch_gpu):
     """agents/MPPPO/MPPPO.py end to end on the environment it instantiates (MO_FJSSP_discretes):
     5 policies, completion / tardiness normalisers from the single-objective runs, evolution step."""
@@ -155,8 +187,14 @@ def _dyn_instances(n, seed0, S=2, M=6, max_windows=2):
     prm = fi.GenParams(R_min=3, R_max=4, J_min=2, J_max=3, M=M, p_min=5, p_max=40, N_min=1, N_max=3, S=S, DDT=1.0,
                        t_si_min=100.0, t_si_max=200.0)
     for i in range(n):
-        s.generate(i, seed0 + i, prm)
-        s.generate_machine_data(i, seed0 + i, max_windows=max_windows, window_gap=(10, 80), window_len=(3, 20))
+        seed = seed0 + i
+        while True:
+            s.generate(i, seed, prm)
+            p = np.asarray(s.arrays(i).p)
+            if (p.reshape(-1, M) > 0).any(axis=0).all():     # the reference divides by a machine's operation count
+                break
+            seed += 1000003
+        s.generate_machine_data(i, seed, max_windows=max_windows, window_gap=(10, 80), window_len=(3, 20))
     return s.solve_fluid()
 
 
@@ -240,6 +278,44 @@ def test_da3c_and_sac_controller_on_mo_dfjsp(torch_gpu, tmp_path):
     assert ((st & ~4) == 0).all()
     rw = sac.memory.rewards[:len(sac.memory)]
     assert bool(torch.isfinite(rw).all()) and float(rw.max()) <= 0.0          # every objective only grows
+
+
+def test_config5_full_size_sac_controller_on_4096_dynamic_envs(torch_gpu, tmp_path):
+    """BASELINE configs[4] at its full size on the environment side: 4096 MO_DFJSP_breakdown envs (two orders:
+    every episode re-solves the fluid LP at the second order's arrival, breakdown windows on every machine), the
+    SAC-discrete controller choosing among three lower policies of the reference's shape for one full episode
+    of every env.  Every env finishes, every arrival got its LP, rewards only ever decrease the objectives."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedMODFJSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.A3C import DA3C
+    from deep_reinforcement_learning_for_fjsp_amd.agents.HMPSAC.SAC_Discrete import SAC_Discrete
+    N = 4096
+    small = BatchedMODFJSP(_dyn_instances(8, 400), rng_seed=2)
+    torch.manual_seed(0)
+    big = DA3C(lambda: small, small, reward_policy=0, seed=9, max_steps=400)      # reference-shaped (3 x 200) lower nets
+    for policy in (0, 1, 2):
+        folder = tmp_path / ("policy_networks_v5.%d" % (policy + 1))
+        folder.mkdir()
+        big.save_actor_model(str(folder))
+    insts = _dyn_instances(N, 9000)
+    env = BatchedMODFJSP(insts, rng_seed=4)
+    sac = SAC_Discrete(env, lower_policies=str(tmp_path), hidden_size=32, hidden_layer=2, seed=1, max_steps=400,
+                       hyper={"min_steps_before_learning": 20000, "update_every_n_steps": 40000, "batch_size": 256,
+                              "learning_updates_per_learning_session": 1})
+    out = sac.run_n_episodes(1)
+    assert len(out) == 1 and all(np.isfinite(v) and v >= 0 for v in out[0])
+    r = env.read()
+    assert bool((r["done"] == 1).all())
+    assert ((r["status"].cpu().numpy() & ~4) == 0).all()
+    n_ops = np.array([int((insts.arrays(i).count.sum(0) * insts.arrays(i).Jr).sum()) for i in range(0, N, 64)])
+    assert np.array_equal(r["step_count"].cpu().numpy()[::64], n_ops)             # one step per operation of every order
+    # one LP per env and episode played (the second order's arrival; reset-time LPs are solved with the instances);
+    # the controller plays the three lower policies once for its normalisers before its own episode
+    assert env.batch.lp_solves >= N and env.batch.lp_solves % N == 0
+    assert sac.learn_sessions > 0 and all(np.isfinite(v) for v in sac.last_losses)
+    rw = sac.memory.rewards[:len(sac.memory)]
+    assert bool(torch.isfinite(rw).all()) and float(rw.max()) <= 0.0
+    assert bool((r["energy_consumption"] > 0).all()) and bool((r["makespan"] > 0).all())
 
 
 def test_da3c_on_so_dfjsp(torch_gpu):

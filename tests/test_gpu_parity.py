@@ -68,10 +68,13 @@ def test_step_kernel_matches_reference_fixtures(torch_gpu, suite):
         H.assert_state_close(st0[e], ep["state0"], "%s ep %d reset" % (suite, e))
     states = np.zeros((T, len(eps), 20)); rewards = np.zeros((T, len(eps))); dones = np.zeros((T, len(eps)), np.uint8)
     clocks = np.zeros((T, len(eps)), np.int64); delays = np.zeros((T, len(eps)), np.int64)
+    km = np.zeros((T, len(eps), 2), np.int16)
+    tr = torch.zeros(len(eps), 2, dtype=torch.int16, device=b.device)
     for t in range(T):
-        s, r, d = b.step(actions[t])
+        s, r, d = b.step(actions[t], trace_out=tr)
         rd = b.read()
         states[t] = s.cpu().numpy(); rewards[t] = r.cpu().numpy(); dones[t] = d.cpu().numpy()
+        km[t] = tr.cpu().numpy()
         clocks[t] = rd["step_time"].cpu().numpy(); delays[t] = rd["delay_time_sum"].cpu().numpy()
     final = b.read()
     tend = b.machine_time_end().cpu().numpy()
@@ -79,6 +82,10 @@ def test_step_kernel_matches_reference_fixtures(torch_gpu, suite):
     for e, ep in enumerate(eps):
         Te = ep["T"]
         tag = "%s episode %d (%s)" % (suite, e, insts[ep["inst"]].name)
+        # what the rule pair resolved to, step by step (task_select / machine_select, SO_FJSSP.py:173-174)
+        assert np.array_equal(km[:Te, e, 0], ep["k"]), tag + " chosen operation type"
+        assert np.array_equal(km[:Te, e, 1], ep["m"]), tag + " chosen machine"
+        assert (km[Te:, e] == -1).all(), tag + " (k, m) of an env that did not step"
         assert np.array_equal(H.bits(rewards[:Te, e]), H.bits(ep["reward"])), tag + " reward"
         assert np.array_equal(dones[:Te, e], ep["done"]), tag + " done"
         assert np.array_equal(clocks[:Te, e], ep["step_time"]), tag + " step_time"
@@ -650,3 +657,113 @@ def test_error_behaviour(torch_gpu):
         st, r, d = mo.step(3, weight_vector=(1, 0))
         tot += r
     assert -tot == mo.completion_time == max(v.time_end for v in mo.machine_dict.values())
+
+
+def test_shards_concatenate_to_the_unsharded_batch(torch_gpu):
+    """results are identical for any number of GPUs.  Two half batches built the way two ranks
+    build them (instances, action tensor and random.choice streams from the GLOBAL env id) replay, env for env
+    and bit for bit, what the unsharded batch does -- the random rules (task rule 6, machine rule 5) included."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, global_actions
+    N, T = 96, 52
+    whole = fi.InstanceSet(N).generate_range(7000, fi.bench_10x5_params()).solve_fluid()
+    acts = global_actions(11, 0, N, T, 6, 5)
+    acts[:, ::3] = (5, 4)                            # a third of the envs play random.choice / random.choice only
+    def play(insts, n, first_env, a):
+        b = EnvBatch(insts, n, rng_seed=77, first_env=first_env)
+        out = [b.reset().clone()]
+        tr = torch.zeros(n, 2, dtype=torch.int16, device=b.device)
+        kms, rws = [], []
+        a = torch.from_numpy(np.ascontiguousarray(a)).to(b.device)
+        for t in range(T):
+            s, r, _ = b.step(a[t], autoreset=True, trace_out=tr)
+            out.append(s.clone()); kms.append(tr.clone()); rws.append(r.clone())
+        fin = b.read()
+        return (torch.stack(out).cpu().numpy(), torch.stack(kms).cpu().numpy(), torch.stack(rws).cpu().numpy(),
+                fin["delay_time_sum"].cpu().numpy(), fin["makespan"].cpu().numpy())
+    ref = play(whole, N, 0, acts)
+    assert (ref[1] >= 0).all()
+    for lo, hi in ((0, 40), (40, 96)):               # uneven shards, the second one not starting at a multiple of 4 x 8
+        part = fi.InstanceSet(hi - lo).generate_range(7000 + lo, fi.bench_10x5_params()).solve_fluid()
+        a = global_actions(11, lo, hi - lo, T, 6, 5)
+        a[:, (-lo) % 3::3] = (5, 4)
+        assert np.array_equal(a, acts[:, lo:hi])
+        got = play(part, hi - lo, lo, a)
+        assert np.array_equal(H.bits(got[0]), H.bits(ref[0][:, lo:hi])), "states of shard [%d, %d)" % (lo, hi)
+        assert np.array_equal(got[1], ref[1][:, lo:hi]), "chosen (k, m) of shard [%d, %d)" % (lo, hi)
+        assert np.array_equal(H.bits(got[2]), H.bits(ref[2][:, lo:hi]))
+        assert np.array_equal(got[3], ref[3][lo:hi]) and np.array_equal(got[4], ref[4][lo:hi])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_steps_without_a_state_do_not_change_later_states(torch_gpu, variant):
+    """fjsp_env_step with d_state == NULL skips the observation; the next step that returns a state rebuilds
+    v(t-1) first, so every returned state equals the one an always-observing run returns (bit for bit)."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, global_actions
+    N, T = 70, 44                                    # (not a multiple of 4: the last workgroup is partial)
+    insts = fi.InstanceSet(N).generate_range(8100, fi.bench_10x5_params()).solve_fluid()
+    na = {0: (6, 5), 1: (20, 1), 2: (18, 1)}[variant]
+    acts = torch.from_numpy(global_actions(3, 0, N, T, *na)).cuda()
+    mo = None
+    if variant == 2:
+        mo = torch.tensor([[0.5, 0.5, 100.0, 1000.0]], dtype=torch.float64).repeat(N, 1).cuda()
+    a = EnvBatch(insts, N, variant=variant, rng_seed=5)
+    b = EnvBatch(insts, N, variant=variant, rng_seed=5)
+    a.reset(); b.reset()
+    pattern = [True, False, False, True, True, False, True, False, False, False, True]
+    for t in range(T):
+        sa, ra, da = a.step(acts[t], autoreset=True, mo=mo)
+        with_state = pattern[t % len(pattern)]
+        sb, rb, db = b.step(acts[t], autoreset=True, mo=mo, state=with_state)
+        assert torch.equal(ra, rb) and torch.equal(da, db), "step %d" % t
+        if with_state:
+            assert np.array_equal(H.bits(sa.cpu().numpy()), H.bits(sb.cpu().numpy())), "state after step %d" % t
+        else:
+            assert sb is None
+    fa, fb = a.read(), b.read()
+    for k in fa:
+        assert torch.equal(fa[k], fb[k]), k
+    # the fused kernel without a final state, then a per-step call that wants one
+    c = EnvBatch(insts, N, variant=variant, rng_seed=5); c.reset()
+    d = EnvBatch(insts, N, variant=variant, rng_seed=5); d.reset()
+    c.rollout(acts[:10], mo=mo, state=False)
+    for t in range(10):
+        d.step(acts[t], mo=mo)
+    sc, _, _ = c.step(acts[10], mo=mo)
+    sd, _, _ = d.step(acts[10], mo=mo)
+    assert np.array_equal(H.bits(sc.cpu().numpy()), H.bits(sd.cpu().numpy()))
+
+
+def test_wrong_tensor_arguments_are_rejected_before_any_launch(torch_gpu):
+    """The C ABI takes raw pointers; EnvBatch checks every tensor's extent, type and device first."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
+    N = 8
+    b = EnvBatch(fi.InstanceSet(N).generate_range(1, fi.bench_10x5_params()).solve_fluid(), N, variant=2)
+    b.reset()
+    good = torch.zeros(N, 2, dtype=torch.uint8, device=b.device)
+    with pytest.raises(ValueError):
+        b.step(torch.zeros(N, dtype=torch.uint8, device=b.device))              # flat [N] actions
+    with pytest.raises(ValueError):
+        b.step(torch.zeros(N + 1, 2, dtype=torch.uint8, device=b.device))
+    with pytest.raises(ValueError):
+        b.step(good, mo=torch.zeros(N, 3, dtype=torch.float64, device=b.device))
+    with pytest.raises(ValueError):
+        b.step(good, state_out=torch.zeros(N, b.state_size, dtype=torch.float32, device=b.device))
+    with pytest.raises(ValueError):
+        b.step(good, reward_out=torch.zeros(N, dtype=torch.float64))             # host tensor as an output
+    with pytest.raises(ValueError):
+        b.step(good, done_out=torch.zeros(N - 1, dtype=torch.uint8, device=b.device))
+    with pytest.raises(ValueError):
+        b.reset(mask=torch.ones(N - 2, dtype=torch.uint8, device=b.device))
+    with pytest.raises(ValueError):
+        b.reset(out=torch.zeros(N, b.state_size + 1, dtype=torch.float64, device=b.device))
+    with pytest.raises(ValueError):
+        b.rollout(torch.zeros(5, N, dtype=torch.uint8, device=b.device))
+    # inputs of another dtype / on the host are converted, as before
+    b.step(torch.zeros(N, 2, dtype=torch.int64), mo=torch.tensor([[0.0, 1.0, 0.0, 0.0]] * N, dtype=torch.float32))
+    assert int((b.read()["status"] != 0).sum()) == 0

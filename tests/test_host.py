@@ -346,3 +346,50 @@ def test_generated_machine_data_ranges(built):
     for m in range(a.M):
         w = a.bk[off[m]:off[m + 1]]
         assert (w[:, 0] < w[:, 1]).all() and (w[1:, 0] > w[:-1, 1]).all()
+
+
+def test_global_actions_and_seeds_do_not_depend_on_the_sharding():
+    """bench.py / train_ppo.py shard env ids over ranks; what an environment plays is a function of its GLOBAL id."""
+    from deep_reinforcement_learning_for_fjsp_amd.batch import ENV_SEED_STRIDE, global_actions
+    whole = global_actions(4242, 0, 100, 64, 6, 5)
+    assert whole.dtype == np.uint8 and whole.shape == (64, 100, 2)
+    assert whole[..., 0].max() == 5 and whole[..., 1].max() == 4 and whole.min() == 0
+    for lo, hi in ((0, 33), (33, 64), (64, 100)):
+        assert np.array_equal(global_actions(4242, lo, hi - lo, 64, 6, 5), whole[:, lo:hi])
+    assert not np.array_equal(global_actions(4243, 0, 100, 64, 6, 5), whole)
+    # all six task rules and all five machine rules get a fair share
+    h0 = np.bincount(whole[..., 0].ravel(), minlength=6) / whole[..., 0].size
+    h1 = np.bincount(whole[..., 1].ravel(), minlength=5) / whole[..., 1].size
+    assert np.abs(h0 - 1 / 6).max() < 0.02 and np.abs(h1 - 1 / 5).max() < 0.02
+    assert ENV_SEED_STRIDE == 1000003           # (the constant of open_env() in csrc/fjsp_kernels.hip)
+
+
+def test_generated_instances_do_not_depend_on_the_sharding(built):
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    whole = fi.InstanceSet(12).generate_range(500, fi.bench_10x5_params())
+    part = fi.InstanceSet(5).generate_range(507, fi.bench_10x5_params())
+    for i in range(5):
+        a, b = whole.arrays(7 + i), part.arrays(i)
+        assert a.K == b.K and np.array_equal(a.p, b.p) and np.array_equal(a.Jr, b.Jr) and a.delivery == b.delivery
+
+
+def test_tensor_argument_checks():
+    """EnvBatch's guards in front of the raw-pointer C ABI (the negative cases need no GPU)."""
+    import torch
+    from deep_reinforcement_learning_for_fjsp_amd.batch import _as_input, _check_output
+    cpu = torch.device("cpu")
+    a = _as_input("actions", torch.zeros(4, 2, dtype=torch.int64), (4, 2), torch.uint8, cpu)
+    assert a.dtype == torch.uint8 and a.is_contiguous()
+    a = _as_input("actions", torch.zeros(2, 4, dtype=torch.uint8).t(), (4, 2), torch.uint8, cpu)
+    assert a.is_contiguous()
+    assert _as_input("mo", None, (4, 4), torch.float64, cpu) is None
+    with pytest.raises(ValueError):
+        _as_input("actions", torch.zeros(4, dtype=torch.uint8), (4, 2), torch.uint8, cpu)
+    with pytest.raises(ValueError):
+        _as_input("mask", torch.zeros(3, dtype=torch.uint8), (4,), torch.uint8, cpu)
+    ok = torch.zeros(4, 20, dtype=torch.float64)
+    assert _check_output("state_out", ok, (4, 20), torch.float64, cpu) is ok
+    for bad in (torch.zeros(4, 20, dtype=torch.float32), torch.zeros(4, 21, dtype=torch.float64),
+                torch.zeros(20, 4, dtype=torch.float64).t(), [0.0] * 80):
+        with pytest.raises(ValueError):
+            _check_output("state_out", bad, (4, 20), torch.float64, cpu)
