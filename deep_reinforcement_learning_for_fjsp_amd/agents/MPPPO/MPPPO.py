@@ -16,7 +16,16 @@ Two defects of the shipped script are fixed rather than replicated (SURVEY.md ro
 a21): the critic loss is not detached before backward (:319 makes the critic
 never train), and equalise_policies copies `.data` (:375 `algorithm_means`
 raises AttributeError at the end of the first episode).
+Kept as the reference has them (tests/test_ppo_update.py pins both):
+  exploration rate of a round          :240-241         eps = 1 / (1 + episode / denominator), then ONE draw
+                                                        max(0, uniform(eps / 3, eps * 3)) per round -- from the
+                                                        agent's own seeded `random.Random` (the reference uses the
+                                                        unseeded global one), shared by every env of the batch
+  multi_policy_update                  :192-203         policy P scores ITS OWN test objectives under every
+                                                        policy's weight vector and moves towards the policy at
+                                                        the arg-min index (see MPPPO.multi_policy_update)
 """
+import random
 import torch
 import torch.nn.functional as F
 from torch import nn, optim
@@ -373,6 +382,12 @@ def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encod
     return memory, losses
 
 
+def jittered_exploration(episode_number, denominator, rng):
+    """MPPPO.py:240-241: the round's epsilon-random rate, one draw per round."""
+    eps = 1.0 / (1.0 + episode_number / denominator)
+    return max(0.0, rng.uniform(eps / 3.0, eps * 3.0))
+
+
 class PPO(Base_Agent):
     """The agent loop of MPPPO.py:230-270 over a batch of SO_FJSSP environments (BASELINE config 3).
 
@@ -396,6 +411,7 @@ class PPO(Base_Agent):
         self.max_steps = max_steps
         self._holder = {}
         self.global_step_number = 0
+        self._rng = random.Random(seed)
         self._pair = torch.zeros(environment.N, 2, dtype=torch.uint8, device=self.device)
 
     @property
@@ -412,7 +428,7 @@ class PPO(Base_Agent):
         """One batched episode + one learning round. Returns (mean delay_time_sum, mean makespan, losses)."""
         hp = self.hyper_parameters
         if exploration is None:                                                         # :240-241
-            exploration = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])
+            exploration = jittered_exploration(self.episode_number, hp["epsilon_decay_rate_denominator"], self._rng)
         memory, losses = collect_and_learn(self.environment, self.learner, self._holder, exploration,
                                            self.max_steps or 64, self._encode, use_graph=self.use_graph,
                                            pair_div=self.environment.actions_size[1] if self.fused_sampling else None)
@@ -455,11 +471,12 @@ class MPPPO(Base_Agent):
         self.completion_min = float("inf")
         self.tardiness_min = float("inf")
         self._holder = {}
+        self._rng = random.Random(seed)
 
     def run_one_policy_network(self, environment, policy_number, completion=None, tardiness=None):
         """:230-270 for every environment of the batch. Returns per-env (delay_time_sum, completion_time)."""
         hp = self.hyper_parameters
-        eps = 1.0 / (1.0 + self.episode_number / hp["epsilon_decay_rate_denominator"])      # :240
+        eps = jittered_exploration(self.episode_number, hp["epsilon_decay_rate_denominator"], self._rng)   # :240-241
         environment.set_objective(self.weight_vector_dict[policy_number], completion, tardiness)
         collect_and_learn(environment, self.learners[policy_number], self._holder, eps, self.max_steps, lambda a: a,
                           pair_div=0 if self.fused_sampling else None)
@@ -506,9 +523,13 @@ class MPPPO(Base_Agent):
                 self.multi_policy_update(objs)
         return history
 
-    def multi_policy_update(self, policy_objectives):
-        """:192-205: every policy moves (soft update, tau) towards the policy whose test objectives score
-        best under ITS weight vector."""
+    def multi_policy_update(self, policy_objectives, selection="reference"):
+        """:192-203.  selection="reference": as the reference computes it -- for policy P the list
+        [w_p[0] * C_P / C_min + w_p[1] * T_P / T_min for p in policies] scores P's OWN test objectives under every
+        policy's weight vector, and P moves (soft update, tau) towards the policy at the arg-min index.
+        selection="own_weight": the transposed reading (every policy's objectives under P's weight vector; P moves
+        towards the policy that serves P's weights best) -- arguably what was meant, not what the reference does.
+        Returns {policy: index it moved towards}."""
         import copy
         actors = {p: copy.deepcopy(self.learners[p].actor_new) for p in self.policy_tuple}
         critics = {p: copy.deepcopy(self.learners[p].critic) for p in self.policy_tuple}
@@ -516,9 +537,16 @@ class MPPPO(Base_Agent):
         cmin, tmin = max(self.completion_min, 1e-9), max(self.tardiness_min, 1e-9)
         chosen = {}
         for policy in self.policy_tuple:
-            w = self.weight_vector_dict[policy]
-            scores = [w[0] * (policy_objectives[q][0] / cmin) + w[1] * (policy_objectives[q][1] / tmin)
-                      for q in self.policy_tuple]
+            if selection == "reference":
+                c, t = policy_objectives[policy]
+                scores = [self.weight_vector_dict[p][0] * (c / cmin) + self.weight_vector_dict[p][1] * (t / tmin)
+                          for p in self.policy_tuple]
+            elif selection == "own_weight":
+                w = self.weight_vector_dict[policy]
+                scores = [w[0] * (policy_objectives[q][0] / cmin) + w[1] * (policy_objectives[q][1] / tmin)
+                          for q in self.policy_tuple]
+            else:
+                raise ValueError("selection must be 'reference' or 'own_weight'")
             best = scores.index(min(scores))
             chosen[policy] = best
             self.soft_update_of_target_network(actors[best], self.learners[policy].actor_new, tau)

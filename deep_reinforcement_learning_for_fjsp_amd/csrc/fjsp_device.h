@@ -130,6 +130,7 @@ int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStrea
 int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                 uint8_t *done, int16_t *trace_km, hipStream_t st);
 size_t rollout_lds_bytes(const DevBatch &b);
+size_t step_lds_bytes(const DevBatch &b);     // dynamic LDS of one reset / step / arrival workgroup
 int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st);
 // multi-order: resume the envs whose pending LP has been solved (x in e_xin)

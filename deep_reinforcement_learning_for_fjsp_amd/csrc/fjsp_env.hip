@@ -36,6 +36,7 @@ struct fjsp_env {
     uint32_t *h_pending = nullptr;
     uint16_t *h_lp_in = nullptr;
     double *h_lp_x = nullptr;
+    bool failed = false;        // the arrival service failed mid-step: parked envs are in limbo, the handle refuses further steps
     int lp_threads = 0;         // 0 = default (min(host cores, 16))
     int64_t lp_solves = 0;      // order-arrival LPs solved so far
     struct LpPool *pool = nullptr;
@@ -199,8 +200,35 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         }
         for (int r = 0; r < in.R; ++r)
             if (in.Jr[r] > 255) { set_error("more than 255 operations in a kind"); return FJSP_E_UNSUPPORTED; }
-        for (int v : in.p)
+        long long pmax = 0;
+        for (int v : in.p) {
             if (v > 65535) { set_error("processing time above 65535"); return FJSP_E_UNSUPPORTED; }
+            pmax = std::max<long long>(pmax, v);
+        }
+        {
+            // The kernels keep the clock, the machines' time_end and the per-kind tardiness sums in 32-bit integers
+            // (Python integers do not wrap).  Worst case of the clock: every operation in sequence at the largest
+            // processing time, after the last order arrival, stretched by every breakdown window; worst case of a
+            // per-kind sum: every job of the kind late by that much.
+            long long ntasks = 0, jobs_kind_max = 0, t_arr_max = 0, bk_total = 0, due_max = 0;
+            for (int r = 0; r < in.R; ++r) {
+                long long jk = 0;
+                for (int so = 0; so < in.S; ++so) { jk += in.count[(size_t)so * in.R + r]; ntasks += (long long)in.count[(size_t)so * in.R + r] * in.Jr[r]; }
+                jobs_kind_max = std::max(jobs_kind_max, jk);
+            }
+            for (int so = 0; so < in.S; ++so) {
+                t_arr_max = std::max<long long>(t_arr_max, in.arrive[so]);
+                due_max = std::max<long long>(due_max, std::llabs((long long)in.delivery[so]));
+            }
+            if (dyn)
+                for (size_t q = 0; q + 1 < in.bk.size(); q += 2) bk_total += std::max(0, in.bk[q + 1] - in.bk[q]);
+            const long long clock_max = t_arr_max + ntasks * pmax + bk_total;
+            if (clock_max + due_max > 0x7fffffffLL || jobs_kind_max * (clock_max + due_max) > 0x7fffffffLL) {
+                set_error("instance too long for the kernels' 32-bit clocks: (last arrival + operations x max processing time + "
+                          "breakdown windows) x jobs per kind must stay below 2^31");
+                return FJSP_E_UNSUPPORTED;
+            }
+        }
         Kmax = std::max(Kmax, in.K); Mmax = std::max(Mmax, in.M); Jmax = std::max(Jmax, nj);
     }
     int ndev = 0;
@@ -225,6 +253,15 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.state_size = b.n_static + 2 * b.n_obs;
     b.rng_seed = rng_seed;
     b.mord = (Smax > 1 || dyn) ? 1 : 0; b.SP = Smax; b.RP = Rmax;     // MO_DFJSP always runs on the per-env fluid tables
+    if (step_lds_bytes(b) > 160 * 1024) {
+        // four environments per workgroup keep their job tables (8 bytes per job) in the CU's 160 KB of LDS
+        char msg[200];
+        snprintf(msg, sizeof(msg), "instance too large for the kernels' LDS staging: %d jobs need %zu bytes per workgroup, the limit is "
+                 "163840 (about %d jobs at this shape)", Jmax, step_lds_bytes(b), (int)((160 * 1024 / 4 - (30 + 3 * b.KP) * 8 - 256) / 8 / 64 * 64));
+        set_error(msg);
+        delete e;
+        return FJSP_E_UNSUPPORTED;
+    }
     e->src = s; e->first = first;
     const size_t KP = (size_t)b.KP, MP = (size_t)b.MP, JP = (size_t)b.JP, NI = (size_t)n_inst, N = (size_t)n_envs;
     // ---- record layouts (fjsp_device.h)
@@ -453,8 +490,24 @@ namespace {
 // Multi-order batches: after a step launch, solve the fluid LP of every env that stopped at an order
 // arrival (class_FJSSP.py:239 on the live state) with the host simplex and let arrival_kernel finish
 // those steps.  Synchronises the stream: order arrivals make step() blocking for such batches.
+int service_arrivals_impl(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace,
+                          hipStream_t st);
+// A failure inside the service (LP iteration limit, HIP error) leaves envs parked with no way to finish their
+// step: the pending list is emptied, so a later launch cannot run its slots past the staging arrays, and the
+// handle is marked failed: every later step / rollout returns FJSP_E_STATE until the batch is destroyed.
 int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace,
                      hipStream_t st) {
+    const int rc = service_arrivals_impl(e, d_mo, d_state, d_reward, d_done, d_trace, st);
+    if (rc != FJSP_OK) {
+        const std::string why = fjsp_last_error();
+        (void)hipMemsetAsync(e->b.pending_count, 0, 4, st);
+        e->failed = true;
+        set_error("order-arrival service failed (" + why + "); the batch is unusable: destroy it");
+    }
+    return rc;
+}
+int service_arrivals_impl(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace,
+                          hipStream_t st) {
     const DevBatch &b = e->b;
     // (the sync below also orders this call after the previous call's solution upload, so the pinned staging
     // buffers are free again)
@@ -518,6 +571,7 @@ int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *st
 int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
                          double *d_reward, uint8_t *d_done, int16_t *d_trace_km, void *stream) {
     if (!e || !d_actions) { set_error("fjsp_env_step: null argument"); return FJSP_E_ARG; }
+    if (e->failed) { set_error("fjsp_env_step: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
     DeviceGuard guard(e->device);
     if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, d_trace_km, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
@@ -534,6 +588,7 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
 int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t T, int16_t *d_trace_km,
                      double *d_reward, double *d_state_last, void *stream) {
     if (!e || !d_actions || T <= 0) { set_error("fjsp_env_rollout: bad arguments"); return FJSP_E_ARG; }
+    if (e->failed) { set_error("fjsp_env_rollout: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
     DeviceGuard guard(e->device);
     hipStream_t st = (hipStream_t)stream;
     if (!e->b.mord && rollout_lds_bytes(e->b) <= 64 * 1024) {

@@ -1577,8 +1577,8 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
             // take a slot of the service's staging area and leave the LP inputs there: the host fetches the
             // inputs of all parked envs with one copy
             uint32_t slot = 0;
-            if (w.lane == 0) { slot = atomicAdd(b.pending_count, 1u); b.pending_count[1 + slot] = (uint32_t)env; }
-            slot = uniu(slot);
+            if (w.lane == 0) { slot = atomicAdd(b.pending_count, 1u); if (slot < (uint32_t)b.N) b.pending_count[1 + slot] = (uint32_t)env; }
+            slot = min(uniu(slot), (uint32_t)b.N - 1u);     // (N slots: an env parks at most once per service; see service_arrivals)
             wave_sync_global();
             const uint32_t *src = reinterpret_cast<const uint32_t *>(w.er + b.L.e_lpq);     // u16[2][KP] as KP words
             uint32_t *dst = reinterpret_cast<uint32_t *>(b.lp_in + (size_t)slot * 2 * b.KP);
@@ -1756,6 +1756,14 @@ __global__ void read_kernel(DevBatch b, int64_t *delay, int32_t *makespan, int32
 
 // ------------------------------------------------------------------ host launchers
 static inline dim3 grid_for(int N) { return dim3((unsigned)((N + 3) / 4)); }
+// Dynamic LDS beyond the 64 KB default must be allowed per kernel (up to the 160 KB of a gfx950 CU; create refuses
+// batches beyond that, step_lds_bytes()).
+template <class K>
+static inline void allow_lds(K kernel, size_t lds) {
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+size_t step_lds_bytes(const DevBatch &b) { return 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false); }
 
 int launch_fluid_tables(const DevBatch &b, hipStream_t st) {
     const int n = b.n_inst * b.KP;
@@ -1787,8 +1795,9 @@ static int dispatch(const DevBatch &b, F &&f) {
 }
 
 int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStream_t st) {
-    const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    const size_t lds = step_lds_bytes(b);
     if (dispatch(b, [&](auto kc, auto v) {
+            allow_lds(&reset_kernel<decltype(kc)::value, decltype(v)::value>, lds);
             hipLaunchKernelGGL((reset_kernel<decltype(kc)::value, decltype(v)::value>), grid_for(b.N), dim3(256), lds, st, b,
                                mask, state);
         }) != 0) return -1;
@@ -1796,8 +1805,9 @@ int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStrea
 }
 int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                 uint8_t *done, int16_t *trace_km, hipStream_t st) {
-    const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    const size_t lds = step_lds_bytes(b);
     if (dispatch(b, [&](auto kc, auto v) {
+            allow_lds(&step_kernel<decltype(kc)::value, decltype(v)::value>, lds);
             hipLaunchKernelGGL((step_kernel<decltype(kc)::value, decltype(v)::value>), grid_for(b.N), dim3(256), lds, st, b,
                                actions, mo, autoreset, state, reward, done, trace_km);
         }) != 0) return -1;
@@ -1809,9 +1819,7 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
     const size_t lds = rollout_lds_bytes(b);
     if (dispatch(b, [&](auto kc, auto v) {
             constexpr int KC = decltype(kc)::value, V = decltype(v)::value;
-            if (lds > 48 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<KC, V>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allow_lds(&rollout_kernel<KC, V>, lds);
             hipLaunchKernelGGL((rollout_kernel<KC, V>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, T, trace_km, reward,
                                state_last);
         }) != 0) return -1;
@@ -1820,9 +1828,10 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
 
 int launch_arrival(const DevBatch &b, const double *mo, int n_pending, double *state, double *reward, uint8_t *done,
                    int16_t *trace_km, hipStream_t st) {
-    const size_t lds = 4 * lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    const size_t lds = step_lds_bytes(b);
     const dim3 grid((unsigned)((n_pending + 3) / 4));
     auto go = [&](auto kc, auto v) {
+        allow_lds(&arrival_kernel<decltype(kc)::value, decltype(v)::value>, lds);
         hipLaunchKernelGGL((arrival_kernel<decltype(kc)::value, decltype(v)::value>), grid, dim3(256), lds, st, b, mo,
                            n_pending, state, reward, done, trace_km);
     };

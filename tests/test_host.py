@@ -393,3 +393,24 @@ def test_tensor_argument_checks():
                 torch.zeros(20, 4, dtype=torch.float64).t(), [0.0] * 80):
         with pytest.raises(ValueError):
             _check_output("state_out", bad, (4, 20), torch.float64, cpu)
+
+
+def test_create_refuses_instances_beyond_the_32_bit_clock(built):
+    """Clocks / per-kind tardiness sums are 32-bit in the kernels; Python integers do not wrap.  An instance whose
+    worst-case schedule could pass 2^31 is refused at create (before any device is touched)."""
+    from deep_reinforcement_learning_for_fjsp_amd import _capi, instances as fi
+    lib = _capi.lib()
+    s = fi.InstanceSet(1)
+    R, M = 2, 2
+    Jr = np.array([120, 120], np.int32)
+    K = int(Jr.sum())
+    p = np.full((K, M), 65535, np.int32)
+    elig_n = np.full(K, M, np.int32)
+    elig_list = np.tile(np.arange(M, dtype=np.int32), (K, 1))
+    count = np.array([[130, 130]], np.int32)                    # 31 200 operations x 65 535 x 130 jobs of a kind > 2^31
+    s.set_raw(0, Jr, p, elig_n, elig_list, count, np.array([0], np.int32), np.array([10 ** 6], np.int32))
+    s.set_x(0, np.full((K, M), 1.0 / K))
+    h = C.c_void_p()
+    rc = lib.fjsp_env_create(s.handle, 0, 1, 1, 0, 0, 0, C.byref(h))
+    assert rc == -5, rc                                         # FJSP_E_UNSUPPORTED
+    assert b"32-bit clocks" in lib.fjsp_last_error()
