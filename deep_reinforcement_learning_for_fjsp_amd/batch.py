@@ -115,6 +115,10 @@ class EnvBatch(object):
         self.state = torch.zeros(self.N, self.state_size, **f64)
         self.reward = torch.zeros(self.N, **f64)
         self.done = torch.ones(self.N, dtype=torch.uint8, device=self.device)
+        # the per-step call is launch-bound on the host (a few us): pointers of the default outputs and the shape
+        # the action tensor must have are prepared once
+        self._p_state, self._p_reward, self._p_done = _ptr(self.state), _ptr(self.reward), _ptr(self.done)
+        self._act_shape = torch.Size((self.N, 2))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -123,7 +127,9 @@ class EnvBatch(object):
             self._h = None
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # (the raw handle of torch's CURRENT stream on this device, looked up per call: callers switch streams and
+        # capture graphs; torch.cuda.current_stream() builds a Stream object first, five times the cost)
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device_index))
 
     def env_seed(self, e):
         """random.choice stream seed of (local) env e (matches open_env() in fjsp_kernels.hip)."""
@@ -153,22 +159,36 @@ class EnvBatch(object):
         state=False: no state is returned and the kernel skips the observation (rule policies that never look at
         it); later calls that do return a state are unaffected (the library rebuilds v(t-1) first).
         trace_out: int16[N, 2] tensor that receives the chosen (operation type k, machine m) of every env."""
-        actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
-        mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
-        state_out = self.state if state_out is None else _check_output("state_out", state_out, (self.N, self.state_size),
-                                                                       torch.float64, self.device)
-        reward_out = self.reward if reward_out is None else _check_output("reward_out", reward_out, (self.N,),
-                                                                          torch.float64, self.device)
-        done_out = self.done if done_out is None else _check_output("done_out", done_out, (self.N,), torch.uint8, self.device)
+        if not (torch.is_tensor(actions) and actions.dtype is torch.uint8 and actions.shape == self._act_shape
+                and actions.device == self.device and actions.is_contiguous()):
+            actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
+        p_mo = None
+        if mo is not None:
+            mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
+            p_mo = _ptr(mo)
+        if state_out is None:
+            state_out, p_state = self.state, self._p_state
+        else:
+            p_state = _ptr(_check_output("state_out", state_out, (self.N, self.state_size), torch.float64, self.device))
+        if reward_out is None:
+            reward_out, p_reward = self.reward, self._p_reward
+        else:
+            p_reward = _ptr(_check_output("reward_out", reward_out, (self.N,), torch.float64, self.device))
+        if done_out is None:
+            done_out, p_done = self.done, self._p_done
+        else:
+            p_done = _ptr(_check_output("done_out", done_out, (self.N,), torch.uint8, self.device))
         if not state:
-            state_out = None
+            state_out, p_state = None, None
         if trace_out is not None:
             _check_output("trace_out", trace_out, (self.N, 2), torch.int16, self.device)
-            check(self._lib.fjsp_env_step_traced(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, _ptr(state_out),
-                                                 _ptr(reward_out), _ptr(done_out), _ptr(trace_out), self._stream()))
+            rc = self._lib.fjsp_env_step_traced(self._h, C.c_void_p(actions.data_ptr()), p_mo, 1 if autoreset else 0, p_state,
+                                                p_reward, p_done, _ptr(trace_out), self._stream())
         else:
-            check(self._lib.fjsp_env_step(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, _ptr(state_out),
-                                          _ptr(reward_out), _ptr(done_out), self._stream()))
+            rc = self._lib.fjsp_env_step(self._h, C.c_void_p(actions.data_ptr()), p_mo, 1 if autoreset else 0, p_state,
+                                         p_reward, p_done, self._stream())
+        if rc < 0:
+            check(rc)
         return state_out, reward_out, done_out
 
     def rollout(self, actions, trace=True, rewards=True, mo=None, state=True):

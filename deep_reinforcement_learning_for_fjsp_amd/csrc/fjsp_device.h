@@ -106,6 +106,9 @@ struct Layout {
 struct DevBatch {
     int32_t N, n_inst, KC, KP, MP, JP, variant, n_obs, n_static, state_size;
     int32_t mord, SP, RP;    // multi-order batch (S > 1): order / kind paddings of i_oarr, i_ocnt
+    int32_t single_job;      // every kind of every instance has one job and there is one order (10x5, the Brandimarte sets):
+                             // per-(r, j) lists have at most one member, job index == kind index
+    int32_t jcap;            // jobs of the largest instance, rounded up to 16: lanes beyond it load no job words
     uint32_t *pending_count; // [0] number of envs parked at an order arrival by the last launch, [1 + slot] their env ids
     uint16_t *lp_in;         // [slot][2][KP] LP inputs (Q, n_now) of the parked env in that slot (written when it parks)
     double *lp_x;            // [slot][KP][MP] fluid solution of that LP (uploaded by the host service, read by arrival_kernel)

@@ -131,8 +131,10 @@ long py_round(double v) { return (long)std::nearbyint(v); }
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {
+        // (the common case -- the caller is already on the batch's device -- costs one hipGetDevice: the per-step
+        // calls are launch-bound on the host)
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        (void)hipSetDevice(dev);
+        if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
     }
     ~DeviceGuard() {
         if (prev >= 0) (void)hipSetDevice(prev);
@@ -156,6 +158,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         set_error("fjsp_env_create: unknown variant"); return FJSP_E_ARG;
     }
     int Kmax = 0, Mmax = 0, Jmax = 0, Smax = 1, Rmax = 0, Bmax = 1;
+    bool single_job = true;
     for (int i = 0; i < n_inst; ++i) {
         const Instance &in = s->v[(size_t)first + i];
         if (!in.valid) { set_error("fjsp_env_create: instance not populated"); return FJSP_E_STATE; }
@@ -229,6 +232,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
                 return FJSP_E_UNSUPPORTED;
             }
         }
+        for (int r = 0; r < in.R; ++r) single_job = single_job && in.S == 1 && in.R <= 255 && in.count[(size_t)r] == 1;
         Kmax = std::max(Kmax, in.K); Mmax = std::max(Mmax, in.M); Jmax = std::max(Jmax, nj);
     }
     int ndev = 0;
@@ -253,6 +257,8 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.state_size = b.n_static + 2 * b.n_obs;
     b.rng_seed = rng_seed;
     b.mord = (Smax > 1 || dyn) ? 1 : 0; b.SP = Smax; b.RP = Rmax;     // MO_DFJSP always runs on the per-env fluid tables
+    b.single_job = (single_job && !b.mord) ? 1 : 0;
+    b.jcap = std::min(b.JP, (Jmax + 15) / 16 * 16);
     if (step_lds_bytes(b) > 160 * 1024) {
         // four environments per workgroup keep their job tables (8 bytes per job) in the CU's 160 KB of LDS
         char msg[200];

@@ -241,6 +241,7 @@ struct W {
     // batch constants copied out of the kernel argument (keeping a pointer to the argument struct
     // makes the compiler spill it to scratch and re-load fields through memory)
     int KP, MP, JP, n_obs, n_static, state_size;
+    bool single_job;         // DevBatch::single_job
     uint32_t e_jst, e_tend, e_mjob, e_un, e_dyn;
     const double *sstate;
     double fluid_completed_time;
@@ -300,6 +301,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
                                          bool load_state) {
     w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
+    w.single_job = !is_mord_v<V> && b->single_job != 0;
     w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn;
     w.env = env;
     w.lane = (int)__lane_id();
@@ -323,10 +325,14 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int k = c * kWave + w.lane;
-        w.kA[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kA)[k];
         w.kB[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kB)[k];
+        // one job per kind: first job = kind index, one job (nothing to fetch); padding lanes have no job
+        w.kA[c] = 0;
+        if (!w.single_job) w.kA[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kA)[k];
         w.elig[c] = reinterpret_cast<const uint32_t *>(ir + L.i_elig)[k];
-        w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
+        // the file order of the first four machines only matters to CPython's set order beyond 8 machines (fjsp_pyset.h)
+        w.first4[c] = 0;
+        if (MP > 8) w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
         if (is_mord_v<V> && load_state) {      // tables of the last LP of THIS environment
             w.fmask[c] = reinterpret_cast<const uint32_t *>(er + L.e_fmask)[k];
             w.rate_sum[c] = reinterpret_cast<const double *>(er + L.e_rsum)[k];
@@ -339,7 +345,9 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
             w.q0[c] = 0;                     // = jobs of the kind, set below
         }
     }
-    const int32_t due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
+    const int jcap = b->jcap;
+    int32_t due0 = 0;
+    if (w.lane < jcap) due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
     uint32_t jst0 = 0;
     int tend0 = 0, mjob0 = -1, tlast0 = -1, ipw0 = 0;
     double obs0 = 0.0;
@@ -347,7 +355,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     if (V == kDyn && w.lane < MP) ipw0 = reinterpret_cast<const int32_t *>(ir + L.i_ipw)[w.lane];
     EnvScalars sc;      // uniform address: the compiler fetches it with scalar loads, no cross-lane traffic
     if (load_state) {
-        jst0 = reinterpret_cast<const uint32_t *>(er + L.e_jst)[w.lane];
+        if (w.lane < jcap) jst0 = reinterpret_cast<const uint32_t *>(er + L.e_jst)[w.lane];
         const EnvScalars *es = reinterpret_cast<const EnvScalars *>(er);
         sc.t = es->t; sc.step_count = es->step_count; sc.done = es->done; sc.n_unassigned = es->n_unassigned;
         sc.status = es->status; sc.seq_ctr = es->seq_ctr; sc.rng_calls = es->rng_calls; sc.busy = es->busy;
@@ -379,6 +387,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.n_orders = is_mord_v<V> ? uni(h.R >> 16) : 1;       // InstHeader.R carries S in its high half for multi-order batches
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
+        if (w.single_job) w.kA[c] = ((w.kB[c] >> 24) & 2u) ? ((1u << 16) | ((w.kB[c] >> 16) & 0xFFu)) : 0u;
         w.tot[c] = (int)(w.kA[c] >> 16);
         if (!(is_mord_v<V> && load_state)) w.q0[c] = w.tot[c];
     }
@@ -449,10 +458,7 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
     const double td = (double)t;
     // one job per kind (10x5, the Brandimarte sets): every list has at most one member, so the walk below is a
     // handful of selects -- no loop, no divergent branches
-    bool single_job = !is_mord_v<V>;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) single_job = single_job && __ballot((w.kA[c] >> 16) > 1u) == 0;
-    if (single_job) {
+    if (w.single_job) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const uint32_t a = w.kA[c];
@@ -512,18 +518,6 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
     }
 }
 
-// max over the 64 lanes of an f64 (every lane active): butterfly inside each 16-lane row with DPP (two
-// 32-bit moves per step, f64 has no DPP form), the four row results combined through readlane.
-__device__ __forceinline__ double wave_max_f64(double v) {
-#define FJSP_MAX_STEP(ctrl)                                                                      \
-    {                                                                                            \
-        const int lo = DPP(__double2loint(v), ctrl, 0), hi = DPP(__double2hiint(v), ctrl, 0);    \
-        v = fmax(v, __hiloint2double(hi, lo));                                                   \
-    }
-    FJSP_MAX_STEP(0xB1) FJSP_MAX_STEP(0x4E) FJSP_MAX_STEP(0x141) FJSP_MAX_STEP(0x140)
-#undef FJSP_MAX_STEP
-    return fmax(fmax(rld(v, 0), rld(v, 16)), fmax(rld(v, 32), rld(v, 48)));
-}
 __device__ __forceinline__ int wave_max_i32(int v) {
     v = max(v, DPP(v, 0xB1, (int)0x80000000));
     v = max(v, DPP(v, 0x4E, (int)0x80000000));
@@ -532,24 +526,48 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return max(max(rl(v, 0), rl(v, 16)), max(rl(v, 32), rl(v, 48)));
 }
 
+// unsigned max over the 64 lanes (every lane active): four DPP steps inside the 16-lane rows, the four row results
+// combined on the scalar unit
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)DPP((int)v, 0xB1, 0));
+    v = max(v, (uint32_t)DPP((int)v, 0x4E, 0));
+    v = max(v, (uint32_t)DPP((int)v, 0x141, 0));
+    v = max(v, (uint32_t)DPP((int)v, 0x140, 0));
+    return max(max(rlu(v, 0), rlu(v, 16)), max(rlu(v, 32), rlu(v, 48)));
+}
+
 // first-extremum argmax / argmin over the set bits of a ballot (the reference's max(list, key=) / min(list, key=)
 // over a list in kind_task_tuple order: the first element attaining the extremum wins).  The extremum is a
-// wave reduction, the winner the first set bit of ballot(member && key == extremum): a fixed ~30 (f64) /
-// ~15 (i32) instructions instead of a readlane walk of ~17 instructions per candidate.
+// wave reduction, the winner the first set bit of ballot(member && key == extremum).
+//
+// f64 keys are reduced as ORDER-PRESERVING 64-bit integers (sign-magnitude -> biased: negative values
+// complemented, the others with the sign bit set; -0.0 first folded onto +0.0, which compare equal in Python),
+// high word first, then the low word among the lanes that tie on the high word: two 32-bit DPP reductions of
+// one instruction per step, where the f64 form costs two moves, a canonicalisation and a v_max_f64 per step
+// (f64 has no DPP).  The keys are finite (sums and differences of bounded counters): no NaN ordering to care for.
 template <int KC>
 __device__ __forceinline__ int argmax_f64(const uint64_t (&mask)[KC], const double (&key)[KC]) {
     const int lane = (int)__lane_id();
     bool in[KC];
-    double mx = -HUGE_VAL;
+    uint32_t hi[KC], lo[KC];
+    uint32_t mhi = 0, mlo = 0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         if (KC == 1 && (mask[c] & (mask[c] - 1)) == 0) return mask[c] ? (int)__builtin_ctzll(mask[c]) : -1;
         in[c] = ((mask[c] >> lane) & 1ull) != 0;
-        if (mask[c]) mx = fmax(mx, wave_max_f64(in[c] ? key[c] : -HUGE_VAL));
+        const double z = key[c] + 0.0;                                  // -0.0 -> +0.0
+        const uint32_t zh = (uint32_t)__double2hiint(z), zl = (uint32_t)__double2loint(z);
+        const bool neg = (zh >> 31) != 0;
+        hi[c] = in[c] ? (neg ? ~zh : (zh | 0x80000000u)) : 0u;          // members are > 0: a non-member never wins
+        lo[c] = neg ? ~zl : zl;
+        if (mask[c]) mhi = max(mhi, wave_max_u32(hi[c]));
     }
 #pragma unroll
+    for (int c = 0; c < KC; ++c)
+        if (mask[c]) mlo = max(mlo, wave_max_u32(hi[c] == mhi ? lo[c] : 0u));
+#pragma unroll
     for (int c = 0; c < KC; ++c) {
-        const uint64_t hit = __ballot(in[c] && key[c] == mx);
+        const uint64_t hit = __ballot(in[c] && hi[c] == mhi && lo[c] == mlo);
         if (hit) return c * kWave + (int)__builtin_ctzll(hit);
     }
     return -1;
@@ -688,8 +706,9 @@ __device__ __forceinline__ int task_select(W<KC, V> &w, int a0, uint32_t idle) {
     // kind_task_delivery_urgency (:153) = sum(estimated delays) / len(list); only rules 1, 2, 4 read it
     double urg[KC];
     if (a0 == 0 || a0 == 1 || a0 == 3) {
+        // (one job per kind: a list of one, sum / 1.0 == sum; lanes outside the candidate masks are never read)
 #pragma unroll
-        for (int c = 0; c < KC; ++c) urg[c] = w.sum_e[c] / (double)w.nun[c];
+        for (int c = 0; c < KC; ++c) urg[c] = w.single_job ? w.sum_e[c] : w.sum_e[c] / (double)w.nun[c];
     } else {
 #pragma unroll
         for (int c = 0; c < KC; ++c) urg[c] = 0.0;
@@ -774,9 +793,16 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
                                               int *en_sel) {
     const int cs = k_sel >> 6, ls = k_sel & 63;
     const uint32_t elig_s = rlu(pick<KC>(w.elig, cs), ls), fm_s = rlu(pick<KC>(w.fmask, cs), ls);
-    const uint32_t first4 = rlu(pick<KC>(w.first4, cs), ls);
-    const CandList sel = pyset_and(idle, elig_s, first4, false);   // machine_selectable_list :302
-    const CandList fsel = pyset_and(idle, fm_s, 0u, true);         // fluid_machine_selectable_list :303
+    CandList sel, fsel;
+    if (w.MP <= 8) {
+        // machine ids < 8: every CPython set involved iterates in ascending order (fjsp_pyset.h), the lists are masks
+        sel.mask = idle & elig_s; sel.n = __builtin_popcount(sel.mask); sel.packed = 0; sel.asc = true;
+        fsel.mask = idle & fm_s; fsel.n = __builtin_popcount(fsel.mask); fsel.packed = 0; fsel.asc = true;
+    } else {
+        const uint32_t first4 = rlu(pick<KC>(w.first4, cs), ls);
+        sel = pyset_and(idle, elig_s, first4, false);              // machine_selectable_list :302
+        fsel = pyset_and(idle, fm_s, 0u, true);                    // fluid_machine_selectable_list :303
+    }
     if (sel.n == 0) { w.status |= FJSP_ST_NO_EVENT; return -1; }
     // lane m: gap_rj_dict[m][k_sel] (class_FJSSP.py:137-142) and p[m][k_sel]
     double g = 0.0, un = 0.0;
@@ -1076,9 +1102,7 @@ __device__ __forceinline__ void tail_sync() {
 template <int KC, int V>
 __device__ __forceinline__ long long observe_prepare(W<KC, V> &w, bool stats_only, double (&frv)[KC], double (&grv)[KC]) {
     const int K = w.K, M = w.M;
-    bool single_job = true;      // every operation type has exactly one job (10x5, Mk01..10): counts are 0 or 1
-#pragma unroll
-    for (int c = 0; c < KC; ++c) single_job = single_job && !is_mord_v<V> && __ballot((w.kA[c] >> 16) > 1u) == 0;
+    const bool single_job = w.single_job;      // every operation type has exactly one job (10x5, Mk01..10): counts are 0 or 1
     // ---- integer statistics (order-free)
     int task_number = 0, delay_a = 0, delay_e = 0, job_a = 0, job_e = 0;
     const int job_number = w.n_unassigned;

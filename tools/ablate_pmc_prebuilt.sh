@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for l in $LEVELS; do
   if [ "$l" = "0" ]; then unset FJSP_AMD_LIB; else export FJSP_AMD_LIB=$ROOT/.diag/libfjsp_ablate$l.so; fi
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc$l -- python3 $ROOT/tools/run_steps.py 4096 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS SQ_WAIT_ANY SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc$l -- python3 $ROOT/tools/run_steps.py 4096 > /dev/null 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st$l -- python3 $ROOT/tools/run_steps.py 4096 > /dev/null 2>&1
   echo "level $l: $(python3 $ROOT/tools/pmc_means.py $OUT/pmc$l step_kernel 4096) $(python3 $ROOT/tools/kstat.py $OUT/st$l step_kernel)" | tee -a $OUT/summary.txt
 done
