@@ -196,6 +196,19 @@ class DA3C(Base_Agent, Config):
         Returns the test objective."""
         env = self.make_train_env()
         states, actions, rewards, valid = self._rollout(env, self.calculate_new_exploration(env.N))
+        self.learn_from_rollout(states, actions, rewards, valid)
+        self.episode_number += 1
+        objective = self.run_test()
+        if objective < self.objective_min:                                             # :299-301 save_actor_model
+            self.objective_min = objective
+            self.best_state = (copy.deepcopy(self.actor_task_model.state_dict()),
+                               copy.deepcopy(self.actor_machine_model.state_dict()))
+        return objective
+
+    def learn_from_rollout(self, states, actions, rewards, valid):
+        """calculate_total_loss + put_gradients_in_queue + update_shared_model (:363-437,164-187) for a batch of
+        episodes: states [T, N, S] f32, actions [T, N, 2] int64, rewards [T, N] f64, valid [T, N] (1 = a step of the
+        episode).  One optimiser step per network; returns (critic, task, machine) losses."""
         T, N = valid.shape
         G = zscore_returns(episode_returns(rewards, valid, self.hp["discount_rate"]), valid).float()
         flat = states.reshape(T * N, -1)
@@ -212,13 +225,7 @@ class DA3C(Base_Agent, Config):
             torch.nn.utils.clip_grad_norm_(net.parameters(), self.hp["gradient_clipping_norm"])
             opt.step()
         self.last_losses = (float(c_loss.detach()), float(t_loss.detach()), float(m_loss.detach()))
-        self.episode_number += 1
-        objective = self.run_test()
-        if objective < self.objective_min:                                             # :299-301 save_actor_model
-            self.objective_min = objective
-            self.best_state = (copy.deepcopy(self.actor_task_model.state_dict()),
-                               copy.deepcopy(self.actor_machine_model.state_dict()))
-        return objective
+        return self.last_losses
 
     @torch.no_grad()
     def run_test(self):
