@@ -22,6 +22,12 @@ class GenParams(C.Structure):
                 ("DDT", _dbl), ("t_si_min", _dbl), ("t_si_max", _dbl)]
 
 
+class ActorParams(C.Structure):
+    """fjsp_actor_params: device pointers to the f32 parameters of a state_size -> 128 -> 128 -> n_actions actor."""
+    _fields_ = [("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("w3", _vp), ("b3", _vp),
+                ("state_size", _i32), ("hidden", _i32), ("n_actions", _i32)]
+
+
 SIGNATURES = {
     "fjsp_last_error": (_cp, []),
     "fjsp_abi_version": (C.c_int, []),
@@ -63,6 +69,8 @@ SIGNATURES = {
     "fjsp_rollout_clear": (C.c_int, [_vp]),
     "fjsp_rollout_len": (C.c_int, [_vp]),
     "fjsp_rollout_ptr": (_vp, [_vp, _i32]),
+    "fjsp_actor_forward": (C.c_int, [C.POINTER(ActorParams), _vp, _i32, _vp, _vp]),
+    "fjsp_env_rollout_policy": (C.c_int, [_vp, _vp, C.POINTER(ActorParams), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fjsp_policy_sample": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
 }
 

@@ -270,6 +270,65 @@ class FusedSampler(object):
         return self.pair
 
 
+def native_actor_params(actor):
+    """fjsp_actor_params for an ActorNet of the in-kernel shape (state_size <= 32 -> 128 -> 128 -> n_actions <= 32, on
+    the GPU), or None when the network has another shape: device pointers into the nn.Linear parameters themselves
+    (the optimiser updates them in place, so the kernels always read the current policy)."""
+    from ..._capi import ActorParams
+    import ctypes as C
+    lin = [l for l in actor.layers if isinstance(l, nn.Linear)]
+    if len(lin) != 3 or not lin[0].weight.is_cuda:
+        return None
+    S, H, A = lin[0].in_features, lin[0].out_features, lin[2].out_features
+    if H != 128 or lin[1].in_features != 128 or lin[1].out_features != 128 or lin[2].in_features != 128 or S > 32 or A > 32:
+        return None
+    tensors = [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias]
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        return None
+    return ActorParams(*[C.c_void_p(t.data_ptr()) for t in tensors], S, H, A)
+
+
+def native_actor_forward(actor, states64, out=None):
+    """ActorNet.forward through the library's actor kernel (fjsp_actor_forward): f64[n, S] states -> f32[n, A]
+    probabilities, the arithmetic the fused policy rollout performs inside the environment kernel."""
+    from ... import _capi
+    import ctypes as C
+    ap = native_actor_params(actor)
+    if ap is None:
+        raise ValueError("the in-kernel actor is state_size (<= 32) -> 128 -> 128 -> n_actions (<= 32) on the GPU")
+    states64 = states64.contiguous()
+    n = states64.shape[0]
+    probs = torch.empty(n, ap.n_actions, dtype=torch.float32, device=states64.device) if out is None else out
+    stream = C.c_void_p(torch._C._cuda_getCurrentRawStream(states64.device.index))
+    _capi.check(_capi.lib().fjsp_actor_forward(C.byref(ap), C.c_void_p(states64.data_ptr()), n, C.c_void_p(probs.data_ptr()), stream))
+    return probs
+
+
+def fused_policy_rollout(env, learner, memory, fused, old_log_prob, exploration, T):
+    """The whole rollout loop (MPPPO.py:245-252) in ONE launch of fjsp_env_rollout_policy: the actor runs inside the
+    environment kernel, rows go straight into `memory`.  Returns False when the batch / network shape is not
+    supported (multi-order instances, K > 64, another network size): the caller falls back to the per-step loop."""
+    from ... import _capi
+    import ctypes as C
+    ap = native_actor_params(learner.actor_new)
+    if ap is None or ap.state_size != env.state_size:
+        return False
+    batch = env.batch
+    mo = getattr(env, "mo", None)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    memory.clear()
+    state = env.reset()
+    fused.new_round(exploration)
+    stream = C.c_void_p(torch._C._cuda_getCurrentRawStream(batch.device_index))
+    rc = _capi.lib().fjsp_env_rollout_policy(batch._h, memory._h, C.byref(ap), p(fused.eps), p(fused.seed), fused.div, int(T), p(mo),
+                                            p(state), p(fused.flat_actions), p(old_log_prob), p(batch.state), stream)
+    if rc == -5:                      # FJSP_E_UNSUPPORTED
+        return False
+    _capi.check(rc)
+    batch.done.fill_(1)               # (read() reports the per-env flags; the vector mirror is refreshed lazily)
+    return True
+
+
 def _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_action, pair, check_done, fused=None):
     """T vector steps: policy inference, epsilon override, HIP env step, rollout-buffer append (MPPPO.py:245-252).
     `exploration` is a float (eager) or a 0-dim device tensor (graph capture: no host branch on its value);
@@ -281,8 +340,11 @@ def _rollout_body(env, learner, memory, old_log_prob, exploration, T, encode_act
     while t < T:
         active = (done == 0).to(torch.uint8)
         if fused is not None:
-            with torch.no_grad():
-                probs = learner.actor_new(state64.float())
+            if getattr(fused, "native_actor", False):
+                probs = native_actor_forward(learner.actor_new, state64)      # the fused rollout's arithmetic, step by step
+            else:
+                with torch.no_grad():
+                    probs = learner.actor_new(state64.float())
             act_pair = fused.sample(probs, t, old_log_prob[t])
             nxt, rew, dn = env.batch.step(act_pair, mo=getattr(env, "mo", None))
             memory.add_experience(state64, act_pair, rew, nxt, dn, active)
@@ -337,7 +399,8 @@ class GraphedRollout(object):
         return self.memory, self.old_log_prob
 
 
-def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action, use_graph=False, pair_div=None):
+def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encode_action, use_graph=False, pair_div=None,
+                      fused_rollout=False):
     """One batched episode on `env` with `learner`'s policy + one learning round (MPPPO.py:230-270).
 
     env.step(action_tensor) must accept what encode_action(flat_action) returns.  Returns
@@ -359,7 +422,16 @@ def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encod
             fused = FusedSampler(N, T, learner.action_size, pair_div, device)
             memory_holder["fused"] = fused
             memory_holder.pop("graph", None)
-    if use_graph:
+    done_in_kernel = False
+    if fused_rollout and fused is not None:
+        old_log_prob = memory_holder.get("old_log_prob")
+        if old_log_prob is None or old_log_prob.shape != (T, N):
+            old_log_prob = torch.zeros(T, N, device=device)
+            memory_holder["old_log_prob"] = old_log_prob
+        done_in_kernel = fused_policy_rollout(env, learner, memory, fused, old_log_prob, exploration, T)
+    if done_in_kernel:
+        pass
+    elif use_graph:
         g = memory_holder.get("graph")
         if g is None or g.env is not env or g.learner is not learner or g.memory is not memory or g.T != T or g.fused is not fused:
             g = GraphedRollout(env, learner, memory, T, encode_action, fused)
@@ -395,11 +467,14 @@ class PPO(Base_Agent):
     (a // 5, a % 5) of SO_FJSSP's [6, 5] action space."""
 
     def __init__(self, environment, hidden_size=128, hidden_layer=2, seed=0, hyper=None, max_steps=None, use_graph=False,
-                 fused_sampling=False):
+                 fused_sampling=False, fused_rollout=False):
         super().__init__()
         self.environment = environment
         self.use_graph = use_graph
-        self.fused_sampling = fused_sampling
+        self.fused_sampling = fused_sampling or fused_rollout
+        # fused_rollout: the whole rollout loop in one launch with the actor inside the environment kernel
+        # (fjsp_env_rollout_policy); falls back to the per-step loop for shapes the kernel does not take
+        self.fused_rollout = fused_rollout
         self.learner_graph = use_graph
         self.device = environment.device
         self.state_size = environment.state_size
@@ -431,7 +506,8 @@ class PPO(Base_Agent):
             exploration = jittered_exploration(self.episode_number, hp["epsilon_decay_rate_denominator"], self._rng)
         memory, losses = collect_and_learn(self.environment, self.learner, self._holder, exploration,
                                            self.max_steps or 64, self._encode, use_graph=self.use_graph,
-                                           pair_div=self.environment.actions_size[1] if self.fused_sampling else None)
+                                           pair_div=self.environment.actions_size[1] if self.fused_sampling else None,
+                                           fused_rollout=self.fused_rollout)
         self.global_step_number += int(memory.valid[:len(memory)].sum().item())
         self.episode_number += 1
         r = self.environment.read()

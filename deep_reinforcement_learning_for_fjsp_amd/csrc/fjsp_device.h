@@ -139,6 +139,12 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
 // multi-order: resume the envs whose pending LP has been solved (x in e_xin)
 int launch_arrival(const DevBatch &b, const double *mo, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
                    hipStream_t st);
+// policy inside the launch (fjsp_policy.h)
+struct ActorParams;
+struct PolicyRolloutIO;
+size_t policy_rollout_lds_bytes(const DevBatch &b, int S);
+int launch_actor_forward(const ActorParams &ap, const double *state, int n, float *probs, hipStream_t st);
+int launch_rollout_policy(const DevBatch &b, const ActorParams &ap, const PolicyRolloutIO &io, const double *mo, int T, hipStream_t st);
 int launch_read(const DevBatch &b, int64_t *delay, int32_t *makespan, int32_t *completion, int32_t *step_time,
                 int32_t *step_count, uint8_t *done, uint32_t *status, hipStream_t st);
 

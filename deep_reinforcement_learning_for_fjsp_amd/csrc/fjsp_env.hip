@@ -18,6 +18,7 @@
 #include "fjsp_device.h"
 #include "fjsp_host.h"
 #include "fjsp_pyset.h"
+#include "fjsp_policy.h"
 
 using namespace fjsp;
 
@@ -616,6 +617,54 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, 
             if (rc != FJSP_OK) return rc;
         }
     }
+    return FJSP_OK;
+}
+
+namespace {
+bool actor_ok(const fjsp_actor_params *a) {
+    return a && a->w1 && a->b1 && a->w2 && a->b2 && a->w3 && a->b3 && a->hidden == kActorH && a->state_size > 0 &&
+           a->state_size <= 32 && a->n_actions > 0 && a->n_actions <= kActorAP;
+}
+ActorParams actor_of(const fjsp_actor_params *a) {
+    ActorParams p;
+    p.w1 = a->w1; p.b1 = a->b1; p.w2 = a->w2; p.b2 = a->b2; p.w3 = a->w3; p.b3 = a->b3;
+    p.S = a->state_size; p.H = a->hidden; p.A = a->n_actions;
+    return p;
+}
+}  // namespace
+
+int fjsp_actor_forward(const fjsp_actor_params *actor, const double *d_state, int32_t n, float *d_probs, void *stream) {
+    if (!d_state || !d_probs || n <= 0) { set_error("fjsp_actor_forward: bad arguments"); return FJSP_E_ARG; }
+    if (!actor_ok(actor)) { set_error("fjsp_actor_forward: the in-kernel actor is state_size (<= 32) -> 128 -> 128 -> n_actions (<= 32)"); return FJSP_E_UNSUPPORTED; }
+    if (launch_actor_forward(actor_of(actor), d_state, n, d_probs, (hipStream_t)stream) != 0) { set_error("actor_forward_kernel launch failed"); return FJSP_E_HIP; }
+    return FJSP_OK;
+}
+
+int fjsp_env_rollout_policy(fjsp_env *e, fjsp_rollout *buf, const fjsp_actor_params *actor, const float *d_epsilon,
+                            const uint64_t *d_seed, int32_t pair_div, int32_t T, const double *d_mo, const double *d_state_in,
+                            float *d_flat_actions, float *d_log_prob, double *d_state_last, void *stream) {
+    if (!e || !buf || !d_epsilon || !d_seed || !d_state_in || !d_flat_actions || !d_log_prob || !d_state_last || T <= 0 || pair_div < 0) {
+        set_error("fjsp_env_rollout_policy: bad arguments"); return FJSP_E_ARG;
+    }
+    if (e->failed) { set_error("fjsp_env_rollout_policy: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
+    if (buf->N != e->b.N || buf->S != e->b.state_size || buf->T < T || buf->device != e->device) {
+        set_error("fjsp_env_rollout_policy: the rollout buffer does not match the batch (N, state_size, T, device)"); return FJSP_E_ARG;
+    }
+    if (!actor_ok(actor) || actor->state_size != e->b.state_size) {
+        set_error("fjsp_env_rollout_policy: the in-kernel actor is state_size (<= 32) -> 128 -> 128 -> n_actions (<= 32)"); return FJSP_E_UNSUPPORTED;
+    }
+    if (e->b.mord || e->b.KC != 1 || policy_rollout_lds_bytes(e->b, actor->state_size) > 160 * 1024) {
+        set_error("fjsp_env_rollout_policy: single-order batches of at most 64 operation types only"); return FJSP_E_UNSUPPORTED;
+    }
+    DeviceGuard guard(e->device);
+    PolicyRolloutIO io;
+    io.state_in = d_state_in; io.epsilon = d_epsilon; io.seed = d_seed; io.pair_div = pair_div;
+    io.o_state = buf->states; io.o_actions = buf->actions; io.o_reward = buf->rewards; io.o_next = buf->next_states;
+    io.o_done = buf->dones; io.o_valid = buf->valid; io.o_flat = d_flat_actions; io.o_logp = d_log_prob; io.state_last = d_state_last;
+    if (launch_rollout_policy(e->b, actor_of(actor), io, d_mo, T, (hipStream_t)stream) != 0) {
+        set_error("rollout_policy_kernel launch failed"); return FJSP_E_HIP;
+    }
+    buf->len = T;
     return FJSP_OK;
 }
 

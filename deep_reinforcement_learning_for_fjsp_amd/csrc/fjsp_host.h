@@ -52,6 +52,13 @@ int finalize_instance(Instance &in);  // derives koff/K, validates
 
 }  // namespace fjsp
 
+// on-policy rollout buffer (fjsp_rollout_buffer.hip); fjsp_env_rollout_policy (fjsp_env.hip) writes its rows in place
+struct fjsp_rollout {
+    int T = 0, N = 0, S = 0, device = 0, len = 0;
+    float *states = nullptr, *actions = nullptr, *rewards = nullptr, *next_states = nullptr, *dones = nullptr,
+          *valid = nullptr, *returns = nullptr;
+};
+
 struct fjsp_instances {
     std::vector<fjsp::Instance> v;
 };

@@ -44,6 +44,7 @@
 #include "../../include/fjsp_amd.h"
 #include "fjsp_device.h"
 #include "fjsp_pyset.h"
+#include "fjsp_policy.h"
 
 #pragma clang fp contract(off)
 
@@ -1300,11 +1301,15 @@ __device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = fals
 
 // state = [static, v(t), v(t) - v(t-1)]  (SO_FJSSP.py:71-72,257-258); updates obs_prev.
 template <int KC, int V>
-__device__ __forceinline__ void emit_state(W<KC, V> &w, double *state_out, bool zero_gap) {
+__device__ __forceinline__ void emit_state(W<KC, V> &w, double *state_out, bool zero_gap, float *x_lds = nullptr) {
     const int n_obs = w.n_obs, n_static = w.n_static;
     const double cur = w.lane < n_obs ? w.scrL[w.lane] : 0.0;
     const double gap = zero_gap ? cur - cur : cur - w.obs_prev_l;
     if (w.lane < n_obs) w.obs_prev_l = cur;
+    if (x_lds) {                   // the state as the policy reads it: `.float()` of the f64 vector (MPPPO.py:274)
+        if (w.lane < n_static) x_lds[w.lane] = (float)w.sstate[w.lane];
+        if (w.lane < n_obs) { x_lds[n_static + w.lane] = (float)cur; x_lds[n_static + n_obs + w.lane] = (float)gap; }
+    }
     if (state_out) {
         double *o = state_out + (size_t)w.env * w.state_size;
         if (w.lane < n_static) o[w.lane] = w.sstate[w.lane];
@@ -1446,13 +1451,14 @@ __device__ __forceinline__ double step_reward(W<KC, V> &w, const double *mo, lon
 // Second half of step() (SO_FJSSP.py:252-265) by the environment's own wave: observation, reward, bookkeeping.
 // A step that hands no state back skips the observation and marks the kept v(t-1) stale (obs_refresh).
 template <int KC, int V, int RING = 2>
-__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs = true) {
+__device__ __forceinline__ double env_step_finish(W<KC, V> &w, const double *mo, double *state_out, bool need_obs = true,
+                                                  float *x_lds = nullptr) {
     w.step_count++;                                                          // :252
     compute_params<KC, V>(w);
     STAMP(w, 5);
     const long long tard_unproc = observe<KC, V, RING>(w, !need_obs);         // :256
     STAMP(w, 6);
-    if (need_obs) { emit_state<KC, V>(w, state_out, false); w.obs_stale = 0; }
+    if (need_obs) { emit_state<KC, V>(w, state_out, false, x_lds); w.obs_stale = 0; }
     else w.obs_stale = 1;
     STAMP(w, 7);
     return step_reward<KC, V>(w, mo, tard_unproc);
@@ -1471,10 +1477,10 @@ __device__ __forceinline__ void obs_refresh(W<KC, V> &w) {
 
 template <int KC, int V, int RING = 2>
 __device__ __forceinline__ double env_step(W<KC, V> &w, const DevBatch *b, int a0, int a1, const double *mo,
-                                           double *state_out, int *k_out, int *m_out, bool need_obs = true) {
+                                           double *state_out, int *k_out, int *m_out, bool need_obs = true, float *x_lds = nullptr) {
     if (need_obs && w.obs_stale) obs_refresh<KC, V>(w);
     if (!env_step_decide<KC, V, RING>(w, b, a0, a1, k_out, m_out)) return 0.0;
-    return env_step_finish<KC, V, RING>(w, mo, state_out, need_obs);
+    return env_step_finish<KC, V, RING>(w, mo, state_out, need_obs, x_lds);
 }
 
 // ------------------------------------------------------------------------ kernels
@@ -1697,6 +1703,87 @@ __global__ __launch_bounds__(256, (KC == 1 && V == FJSP_VARIANT_SO_FJSSP) ? 4 : 
     store_dynamic<KC, V>(w, true);
 }
 
+// ------------------------------------------------------------------ policy inside the launch
+// Actor forward for a batch of states, one wavefront per state, 16 per workgroup, weights in LDS: the per-step
+// counterpart of what rollout_policy_kernel evaluates in place (same device function, same arithmetic).
+__global__ __launch_bounds__(1024) void actor_forward_kernel(ActorParams ap, const double *state, int n, float *probs) {
+    float *lds = reinterpret_cast<float *>(fjsp_lds);
+    actor_lds_fill(lds, ap, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();
+    const int wave = uni((int)(threadIdx.x >> 6)), lane = (int)__lane_id();
+    const int row = blockIdx.x * 16 + wave;
+    if (row >= n) return;
+    float *xs = lds + actor_lds_floats(ap.S) + (size_t)wave * (32 + kActorH + kActorAP);
+    float *hs = xs + 32, *ps = hs + kActorH;
+    if (lane < ap.S) xs[lane] = (float)state[(size_t)row * ap.S + lane];
+    actor_wave_sync();
+    actor_probs(lds, xs, hs, ps, ap.S, ap.A);
+    if (lane < ap.A) probs[(size_t)row * ap.A + lane] = ps[lane];
+}
+
+// The T-step rollout with the actor inside the launch (replaces the per-step loop MPPPO.py:245-252: policy
+// inference, sampling, env.step, buffer append): one wavefront per environment for the whole episode, sixteen
+// per workgroup sharing the actor's weights in LDS.  Per step: actor_probs on the current state, sample_action
+// by lane 0 (the counter-based stream of fjsp_policy_sample: same seed, same actions as the per-step path),
+// the environment step, the buffer row.  Finished environments idle; their rows are marked invalid.
+template <int KC, int V>
+__global__ __launch_bounds__(1024) void rollout_policy_kernel(DevBatch b, ActorParams ap, PolicyRolloutIO io, const double *mo, int T) {
+    float *lds = reinterpret_cast<float *>(fjsp_lds);
+    actor_lds_fill(lds, ap, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();                                   // (the only workgroup barrier: waves may leave after it)
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int env = blockIdx.x * 16 + wave;
+    if (env >= b.N) return;
+    const uint32_t env_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    unsigned char *wave_lds = fjsp_lds + ((actor_lds_floats(ap.S) * 4 + 255) & ~(size_t)255) +
+                              (size_t)wave * (env_stride + (32 + kActorH + kActorAP) * 4);
+    float *xs = reinterpret_cast<float *>(wave_lds + env_stride);
+    float *hs = xs + 32, *ps = hs + kActorH;
+    W<KC, V> w;
+    open_env<KC, V>(w, &b, env, wave_lds, false, true);
+    compute_params<KC, V>(w);
+    const int S = ap.S, A = ap.A, N = b.N;
+    if (w.lane < S) xs[w.lane] = (float)io.state_in[(size_t)env * S + w.lane];
+    const float eps = io.epsilon[0];
+    const uint64_t seed = io.seed[0];
+    const double *mo_e = mo ? mo + (size_t)env * 4 : nullptr;
+    wave_sync();
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * N + env;
+        const bool live = !w.done && !(w.status & (FJSP_ST_BAD_TASK_RULE | FJSP_ST_BAD_MACHINE_RULE | FJSP_ST_NO_EVENT));
+        if (!live) {
+            if (w.done) w.status |= FJSP_ST_STEP_AFTER_DONE;       // what the per-step loop flags for the same launches
+            // (rows of finished environments are masked by `valid`; they still get finite contents -- the last state,
+            // like the per-step loop leaves there -- because masked arithmetic multiplies them by zero)
+            if (w.lane < S) { io.o_state[row * S + w.lane] = xs[w.lane]; io.o_next[row * S + w.lane] = xs[w.lane]; }
+            if (w.lane == 0) {
+                io.o_valid[row] = 0.0f; io.o_reward[row] = 0.0f; io.o_done[row] = 1.0f;
+                io.o_actions[row * 2] = 0.0f; io.o_actions[row * 2 + 1] = 0.0f; io.o_flat[row] = 0.0f; io.o_logp[row] = 0.0f;
+            }
+            continue;
+        }
+        if (w.lane < S) io.o_state[row * S + w.lane] = xs[w.lane];
+        actor_probs(lds, xs, hs, ps, S, A);
+        int action = 0;
+        float logp = 0.0f;
+        if (w.lane == 0) {
+            const SampledAction sa = sample_action(ps, A, eps, seed, (uint64_t)t, env);
+            action = sa.action; logp = sa.log_prob;
+        }
+        action = uni(action);
+        const int a0 = io.pair_div > 0 ? action / io.pair_div : action, a1 = io.pair_div > 0 ? action % io.pair_div : 0;
+        int k_sel, m_sel;
+        const double reward = env_step<KC, V>(w, &b, a0, a1, mo_e, io.state_last, &k_sel, &m_sel, true, xs);
+        if (w.lane < S) io.o_next[row * S + w.lane] = xs[w.lane];
+        if (w.lane == 0) {
+            io.o_actions[row * 2] = (float)a0; io.o_actions[row * 2 + 1] = (float)a1;
+            io.o_reward[row] = (float)reward; io.o_done[row] = (float)w.done; io.o_valid[row] = 1.0f;
+            io.o_flat[row] = (float)action; io.o_logp[row] = logp;
+        }
+    }
+    store_dynamic<KC, V>(w, false);
+}
+
 // Multi-order: finish the step of every env parked at an order arrival.  The host service has solved the
 // fluid LP of the env's live state (class_FJSSP.py:239) and left x in the env record; this kernel runs
 // update_fluid_parameter (:282-306) for that env, then the second half of step().
@@ -1846,6 +1933,29 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
             allow_lds(&rollout_kernel<KC, V>, lds);
             hipLaunchKernelGGL((rollout_kernel<KC, V>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, T, trace_km, reward,
                                state_last);
+        }) != 0) return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+size_t policy_rollout_lds_bytes(const DevBatch &b, int S) {
+    return ((actor_lds_floats(S) * 4 + 255) & ~(size_t)255) +
+           16 * (lds_bytes_per_wave(b.JP, b.MP, b.KP, false) + (32 + kActorH + kActorAP) * 4);
+}
+int launch_actor_forward(const ActorParams &ap, const double *state, int n, float *probs, hipStream_t st) {
+    const size_t lds = actor_lds_floats(ap.S) * 4 + 16 * (32 + kActorH + kActorAP) * 4;
+    allow_lds(&actor_forward_kernel, lds);
+    hipLaunchKernelGGL(actor_forward_kernel, dim3((unsigned)((n + 15) / 16)), dim3(1024), lds, st, ap, state, n, probs);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_rollout_policy(const DevBatch &b, const ActorParams &ap, const PolicyRolloutIO &io, const double *mo, int T, hipStream_t st) {
+    if (b.mord || b.KC != 1) return -1;                 // order arrivals need the host LP service between steps; K <= 64
+    const size_t lds = policy_rollout_lds_bytes(b, ap.S);
+    if (dispatch(b, [&](auto kc, auto v) {
+            constexpr int KC = decltype(kc)::value, V = decltype(v)::value;
+            if constexpr (!is_mord_v<V> && KC == 1) {
+                allow_lds(&rollout_policy_kernel<KC, V>, lds);
+                hipLaunchKernelGGL((rollout_policy_kernel<KC, V>), dim3((unsigned)((b.N + 15) / 16)), dim3(1024), lds, st, b, ap, io, mo, T);
+            }
         }) != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

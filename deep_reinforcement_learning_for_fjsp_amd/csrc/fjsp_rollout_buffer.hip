@@ -11,14 +11,9 @@
 
 #include "../../include/fjsp_amd.h"
 #include "fjsp_host.h"
+#include "fjsp_policy.h"
 
 #pragma clang fp contract(off)
-
-struct fjsp_rollout {
-    int T = 0, N = 0, S = 0, device = 0, len = 0;
-    float *states = nullptr, *actions = nullptr, *rewards = nullptr, *next_states = nullptr, *dones = nullptr,
-          *valid = nullptr, *returns = nullptr;
-};
 
 namespace {
 
@@ -67,41 +62,19 @@ bool ok(hipError_t e, const char *what) {
 }
 
 
-__device__ inline uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-// pick_action_and_log_prob (agents/MPPPO/MPPPO.py:272-284) for one vector step, one thread per env:
-// Categorical(probs).sample() by inverse CDF over the normalised probabilities, the epsilon-random override
-// (:279-280), log_prob of the taken action with torch's clamp of the normalised probability to
-// [eps, 1 - eps], and the action in the environment's encoding (pair (a / div, a % div), or (a, 0) for the
-// flat-action environments).  Replaces the ~15 small launches torch needs for the same thing.
+// pick_action_and_log_prob (agents/MPPPO/MPPPO.py:272-284) for one vector step, one thread per env: the sampler of
+// fjsp_policy.h (shared with the fused policy rollout), and the action in the environment's encoding (pair
+// (a / div, a % div), or (a, 0) for the flat-action environments).  Replaces the ~15 small launches torch needs for
+// the same thing.
 __global__ void policy_sample_kernel(const float *probs, int N, int A, int div, const float *epsilon, const uint64_t *seed,
                                      uint64_t counter, uint8_t *pair, float *action_out, float *logp_out) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
-    const float *p = probs + (size_t)env * A;
-    float total = 0.0f;
-    for (int a = 0; a < A; ++a) total += p[a];
-    const uint64_t r = mix64(seed[0] ^ mix64(counter * 0x100000001B3ULL + (uint64_t)env));
-    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);                 // [0, 1)
-    const float v = (float)((r >> 16) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    int action = A - 1;
-    float acc = 0.0f;
-    const float target = u * total;
-    for (int a = 0; a < A; ++a) {
-        acc += p[a];
-        if (acc > target) { action = a; break; }
-    }
-    if (v <= epsilon[0]) action = (int)(mix64(r) % (uint64_t)A);               // random.randint(0, A - 1)
-    float pn = p[action] / total;
-    pn = fminf(fmaxf(pn, 1.1920929e-07f), 1.0f - 1.1920929e-07f);
-    logp_out[env] = logf(pn);
-    action_out[env] = (float)action;
-    pair[env * 2] = (uint8_t)(div > 0 ? action / div : action);
-    pair[env * 2 + 1] = (uint8_t)(div > 0 ? action % div : 0);
+    const fjsp::SampledAction sa = fjsp::sample_action(probs + (size_t)env * A, A, epsilon[0], seed[0], counter, env);
+    logp_out[env] = sa.log_prob;
+    action_out[env] = (float)sa.action;
+    pair[env * 2] = (uint8_t)(div > 0 ? sa.action / div : sa.action);
+    pair[env * 2 + 1] = (uint8_t)(div > 0 ? sa.action % div : 0);
 }
 
 }  // namespace

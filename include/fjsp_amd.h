@@ -249,6 +249,32 @@ int fjsp_rollout_len(const fjsp_rollout *b);
  * 3 next_states f32[T][N][S], 4 dones f32[T][N], 5 valid f32[T][N], 6 returns f32[T][N]. */
 void *fjsp_rollout_ptr(fjsp_rollout *b, int32_t which);
 
+/* The actor of the on-policy agents (ActorNet, agents/MPPPO/MPPPO.py:31-48) at the size of BASELINE config 3:
+ * state_size -> 128 -> 128 -> n_actions, Linear + ReLU twice, Linear, softmax.  Device pointers to the f32
+ * parameters in torch's layout (weight[out][in] row-major): what nn.Linear holds.  state_size <= 32, hidden == 128,
+ * n_actions <= 32. */
+typedef struct fjsp_actor_params {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    int32_t state_size, hidden, n_actions;
+} fjsp_actor_params;
+
+/* ActorNet.forward (MPPPO.py:44-48) for n states: d_state f64[n][state_size] (converted with `.float()` like
+ * MPPPO.py:274) -> d_probs f32[n][n_actions].  The same device code the fused rollout below evaluates in place. */
+int fjsp_actor_forward(const fjsp_actor_params *actor, const double *d_state, int32_t n, float *d_probs, void *stream);
+
+/* run_one_policy_network's rollout loop (MPPPO.py:245-252: pick_action_and_log_prob, env.step, save_experience)
+ * for T vector steps in ONE launch: the actor is evaluated inside the environment kernel, actions are drawn from
+ * the stream of fjsp_policy_sample (same *d_seed, counter = step index: the same actions as the per-step path
+ * actor -> fjsp_policy_sample -> fjsp_env_step, bit for bit), and every step's row goes straight into `buf`
+ * (as fjsp_rollout_append writes it; rows of envs that had finished are marked invalid, buf's length becomes T).
+ * d_state_in f64[N][S]: the states the rollout starts from (what fjsp_env_reset returned); d_flat_actions /
+ * d_log_prob f32[T][N]: the sampled action index and its log-probability; d_state_last f64[N][S] receives every
+ * env's latest state.  d_mo as in fjsp_env_step.  Single-order batches of at most 64 operation types;
+ * FJSP_E_UNSUPPORTED otherwise (callers fall back to the per-step loop). */
+int fjsp_env_rollout_policy(fjsp_env *e, fjsp_rollout *buf, const fjsp_actor_params *actor, const float *d_epsilon,
+                            const uint64_t *d_seed, int32_t pair_div, int32_t T, const double *d_mo, const double *d_state_in,
+                            float *d_flat_actions, float *d_log_prob, double *d_state_last, void *stream);
+
 /* pick_action_and_log_prob (agents/MPPPO/MPPPO.py:272-284) for one vector step in ONE launch: samples
  * Categorical(d_probs[env]) (f32[n][n_actions], the actor's softmax output), applies the epsilon-random
  * override (*d_epsilon, device scalar so that captured graphs can change it), and writes the flat action

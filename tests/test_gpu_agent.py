@@ -343,3 +343,109 @@ def test_da3c_on_so_dfjsp(torch_gpu):
     assert any(not torch.equal(b, p) for b, p in zip(before, tr.actor_task_model.parameters()))
     assert tr.actor_machine_model.layers_2[0].in_features == 21 and tr.actor_task_model.layers_1[-1].out_features == 6
 
+
+
+def test_native_actor_matches_the_torch_actor(torch_gpu):
+    """fjsp_actor_forward (the actor MLP as the fused policy rollout evaluates it: f32 fmaf chains in a fixed order,
+    weights in LDS) against ActorNet.forward in PyTorch-ROCm f32 on the same weights and states: 1e-5 relative on the
+    probabilities (tolerance of a differently ordered f32 sum over <= 128 terms), rows sum to 1."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import ActorNet, native_actor_forward, native_actor_params
+    torch.manual_seed(3)
+    for S, A, n in ((20, 30, 1000), (25, 18, 37), (18, 20, 16)):
+        net = ActorNet(S, 128, 2, A).cuda()
+        states = (torch.randn(n, S, dtype=torch.float64, device="cuda") * 3.0)
+        with torch.no_grad():
+            want = net(states.float())
+        got = native_actor_forward(net, states)
+        assert got.shape == want.shape
+        assert float((got.sum(1) - 1).abs().max()) < 1e-5
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert native_actor_params(ActorNet(20, 64, 2, 30).cuda()) is None          # other shapes: no in-kernel path
+    assert native_actor_params(ActorNet(20, 128, 3, 30).cuda()) is None
+
+
+@pytest.mark.parametrize("which", ["so_fjssp", "mo_discretes"])
+def test_fused_policy_rollout_equals_the_per_step_path(torch_gpu, which):
+    """fjsp_env_rollout_policy (actor inside the environment kernel, one launch per rollout) against the per-step
+    loop it replaces (MPPPO.py:245-252 as actor kernel -> fjsp_policy_sample -> fjsp_env_step -> fjsp_rollout_append)
+    with the same weights, seed and exploration rate: sampled actions, log-probabilities, rewards, states, next
+    states, done flags and the valid mask of every row, and the environments' final attributes -- bit for bit."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedMOFJSSP, BatchedSOFJSSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO import MPPPO as M
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.Buffer import RolloutBuffer
+    N, T = 150, 56                                    # (not a multiple of 16: the last workgroup is partial)
+    insts = fi.InstanceSet(N).generate_range(3000, fi.bench_10x5_params()).solve_fluid()
+    if which == "so_fjssp":
+        mk = lambda: BatchedSOFJSSP(insts, rng_seed=9)
+        S, A, div = 20, 30, 5
+    else:
+        def mk():
+            e = BatchedMOFJSSP(insts, rng_seed=9)
+            e.set_objective((0.5, 0.5), torch.full((N,), 60.0, dtype=torch.float64), torch.full((N,), 400.0, dtype=torch.float64))
+            return e
+        S, A, div = 25, 18, 0
+    torch.manual_seed(11)
+    learner = M.PPOLearner(S, A, 128, 2, 2, device=torch.device("cuda", 0), seed=5)
+    out = {}
+    for mode in ("per_step", "fused"):
+        env = mk()
+        memory = RolloutBuffer(T, N, S, device=0)
+        fused = M.FusedSampler(N, T, A, div, torch.device("cuda", 0))
+        fused.rounds = 41                              # the same sampling stream for both runs
+        old_log_prob = torch.zeros(T, N, device="cuda")
+        torch.manual_seed(77)
+        if mode == "per_step":
+            fused.native_actor = True
+            fused.new_round(0.15)
+            M._rollout_body(env, learner, memory, old_log_prob, 0.15, T, lambda a: a, None, False, fused)
+        else:
+            assert M.fused_policy_rollout(env, learner, memory, fused, old_log_prob, 0.15, T)
+        assert len(memory) == T
+        torch.cuda.synchronize()
+        valid = memory.valid[:T].clone()
+        r = env.read()
+        keep = lambda x: torch.where((valid if x.dim() == 2 else valid.unsqueeze(-1)) > 0, x, torch.zeros_like(x))   # valid rows only
+        assert all(bool(torch.isfinite(x).all()) for x in (memory.states[:T], memory.next_states[:T], old_log_prob))
+        out[mode] = dict(valid=valid, flat=keep(fused.flat_actions[:T]), logp=keep(old_log_prob),
+                         states=keep(memory.states[:T]), nxt=keep(memory.next_states[:T]),
+                         rewards=keep(memory.rewards[:T]), dones=keep(memory.dones[:T]), actions=keep(memory.actions[:T]),
+                         final_state=env.batch.state.clone(), delay=r["delay_time_sum"], makespan=r["makespan"], steps=r["step_count"],
+                         status=r["status"] & ~4)
+    a, b = out["per_step"], out["fused"]
+    assert int(a["valid"].sum()) == int(a["steps"].sum()) and bool((a["steps"] > 0).all())
+    for k in a:
+        if not torch.equal(a[k], b[k]):
+            bad = (a[k] != b[k]).nonzero()
+            raise AssertionError("%s differs at %d places, first %s: %r vs %r" % (
+                k, bad.shape[0], bad[0].tolist(), a[k][tuple(bad[0].tolist())].item(), b[k][tuple(bad[0].tolist())].item()))
+    assert int(a["status"].abs().sum()) == 0
+    assert len(set(a["flat"].long().flatten().tolist())) > A // 2              # the policy did sample around
+
+
+def test_ppo_rounds_with_the_fused_policy_rollout(torch_gpu):
+    """PPO(fused_rollout=True): learning rounds on top of the one-launch rollout, same invariants as the per-step agent."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.environments import BatchedSOFJSSP
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import PPO
+    N = 1024
+    s = fi.InstanceSet(N).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
+    env = BatchedSOFJSSP(s, rng_seed=3)
+    torch.manual_seed(0)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=True, fused_rollout=True)
+    K = np.array([s.dims(i)["K"] for i in range(N)])
+    before = [p.detach().clone() for p in agent.learner.actor_new.parameters()]
+    for rnd in range(3):
+        tard, mk, (c_loss, a_loss) = agent.run_one_policy_network()
+        assert np.isfinite(tard) and np.isfinite(mk) and np.isfinite(c_loss) and np.isfinite(a_loss)
+        r = env.read()
+        assert bool((r["done"] == 1).all()) and int(((r["status"] & ~4) != 0).sum()) == 0
+        assert np.array_equal(r["step_count"].cpu().numpy(), K)
+        valid = agent.memory.valid[:len(agent.memory)]
+        assert np.array_equal(valid.sum(0).cpu().numpy().astype(np.int64), K)
+        tot = (agent.memory.rewards[:len(agent.memory)].double() * valid.double()).sum(0)
+        assert torch.equal(-tot.long(), r["delay_time_sum"])
+    assert any(not torch.equal(b, p) for b, p in zip(before, agent.learner.actor_new.parameters()))
