@@ -71,6 +71,11 @@ SIGNATURES = {
     "fjsp_rollout_ptr": (_vp, [_vp, _i32]),
     "fjsp_actor_forward": (C.c_int, [C.POINTER(ActorParams), _vp, _i32, _vp, _vp]),
     "fjsp_env_rollout_policy": (C.c_int, [_vp, _vp, C.POINTER(ActorParams), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_ppo_partials": (C.c_int, [_i32]),
+    "fjsp_ppo_actor_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_ppo_critic_loss": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_relu_bwd_bias": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "fjsp_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     "fjsp_policy_sample": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
 }
 

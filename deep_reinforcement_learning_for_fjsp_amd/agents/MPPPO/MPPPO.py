@@ -128,6 +128,8 @@ class PPOLearner(object):
         self.hp = dict(HYPER)
         self.hp.update(hyper or {})
         self.device = torch.device(device)
+        self.fused_learn = True            # GPU batches of >= 32 k samples train through agents/fused_mlp.py
+        self._fused = None
         gen_state = torch.random.get_rng_state()
         torch.manual_seed(seed)            # identical initial parameters on every rank
         self.actor_new = ActorNet(state_size, hidden_size, hidden_layer, action_size).to(self.device)
@@ -140,6 +142,8 @@ class PPOLearner(object):
         self.actor_optimizer = optim.Adam(self.actor_new.parameters(), **adam)
         self.critic_optimizer = optim.Adam(self.critic.parameters(), **adam)
         self.graph_learn = False         # replay the learning round from a HIP graph once its sample count repeats
+        if self.device.type == "cuda":
+            self._fused_nets()           # re-homes the parameters into flat buffers NOW: before any graph captures their addresses
         self._learn_graph = None
         self.action_size = action_size
         self.train_critic = train_critic
@@ -174,6 +178,8 @@ class PPOLearner(object):
             states, actions, old_log_prob, returns = states[idx], actions[idx], old_log_prob[idx], returns[idx]
             vmask = torch.ones(idx.shape[0], dtype=torch.bool, device=states.device)
         m = vmask.to(states.dtype)
+        # big GPU batches (rows of finished environments already dropped): the fused trainer (agents/fused_mlp.py)
+        self._use_fused = self.fused_learn and states.is_cuda and states.shape[0] >= (1 << 15) and self._fused_nets() is not None
         if self.graph_learn and states.is_cuda and not fdist.is_distributed():
             return self._learn_graphed(states, actions, old_log_prob, returns, m)
         count = fdist.all_reduce_scalar_sum(m.sum())          # global number of samples
@@ -186,6 +192,8 @@ class PPOLearner(object):
         hp = self.hp
         if count is None:
             count = m.sum()                # single process: the sample count as a device scalar (no host round trip)
+        if getattr(self, "_use_fused", False):
+            return self._learn_body_fused(states, actions, old_log_prob, returns, count)
         with torch.no_grad():
             advantages = returns - self.critic(states).squeeze(1)                       # :263
         c_loss = a_loss = None
@@ -231,6 +239,46 @@ class PPOLearner(object):
             dst.copy_(src)
         g["graph"].replay()
         return float(g["out"][0]), float(g["out"][1])
+
+    def _fused_nets(self):
+        """(actor trainer, critic trainer) of agents/fused_mlp.py, created on first use; None when a network has another
+        shape than Linear-ReLU-Linear-ReLU-Linear or lives on the CPU."""
+        from .. import fused_mlp
+        if self._fused is None:
+            if not (fused_mlp.supported(self.actor_new.layers, self.device) and fused_mlp.supported(self.critic.layers, self.device)):
+                self._fused = False
+            else:
+                hp = self.hp
+                mk = lambda net: fused_mlp.FusedMLP(net.layers, lr=hp["learning_rate"], eps=1e-4, max_norm=hp["gradient_clipping_norm"])
+                self._fused = (mk(self.actor_new), mk(self.critic))
+        return self._fused or None
+
+    def _learn_body_fused(self, states, actions, old_log_prob, returns, count):
+        """_learn_body on the fused trainer: same iteration structure (:314-323), the dense layers on the library GEMMs,
+        everything between them in csrc/fjsp_ppo.hip; all samples are valid here (the caller dropped the others)."""
+        hp = self.hp
+        actor, critic = self._fused_nets()
+        count = count.to(torch.float32).reshape(1)
+        if fdist.is_distributed():
+            reduce = lambda g: torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM)
+        else:
+            reduce = None
+        actions_f = actions.to(torch.float32).contiguous()
+        states = states.contiguous()
+        advantages = (returns - critic.forward(states).squeeze(1)).contiguous()                    # :263
+        c_loss = a_loss = None
+        for _ in range(hp["learning_iterations_per_round_critic"]):
+            critic.forward(states)
+            c_loss = critic.critic_loss(returns, count)                                           # F.mse_loss, :318
+            if self.train_critic:
+                critic.backward()
+                critic.step(reduce)
+            actor.forward(states)
+            a_loss = actor.actor_loss(actions_f, old_log_prob, advantages, hp["clip_epsilon"], count)   # :325-352
+            actor.backward()
+            actor.step(reduce)
+        self.equalise_policies()
+        return c_loss[0].clone(), a_loss[0].clone()
 
     def equalise_policies(self):
         """:372-375 with the AttributeError fixed."""

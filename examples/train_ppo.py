@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--eager", action="store_true", help="launch every op of the rollout from Python instead of replaying the HIP graph")
+    ap.add_argument("--per-step-rollout", action="store_true",
+                    help="per-step rollout loop (policy, sampler, env kernel, buffer append per vector step) instead of the "
+                         "one-launch rollout with the actor inside the environment kernel")
     args = ap.parse_args()
     import torch
     from deep_reinforcement_learning_for_fjsp_amd import distributed as fd, instances as fi
@@ -35,7 +38,8 @@ def main():
     insts = fi.InstanceSet(N).generate_range(1000 + rank * N, fi.bench_10x5_params()).solve_fluid()
     env = BatchedSOFJSSP(insts, device=local, rng_seed=7, first_env=rank * N)     # streams follow the GLOBAL env id
     torch.manual_seed(1234 + rank)
-    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=not args.eager, fused_sampling=not args.eager)
+    agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=not args.eager, fused_sampling=not args.eager,
+                fused_rollout=not (args.eager or args.per_step_rollout))
     agent.run_one_policy_network()          # warm-up round (allocations, kernel caches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

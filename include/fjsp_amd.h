@@ -285,6 +285,30 @@ int fjsp_policy_sample(const float *d_probs, int32_t n, int32_t n_actions, int32
                        const uint64_t *d_seed, uint64_t counter, uint8_t *d_pair, float *d_action, float *d_log_prob,
                        void *stream);
 
+/* ---- fused pieces of the clipped-PPO learning iteration (agents/MPPPO/MPPPO.py:314-370; csrc/fjsp_ppo.hip).
+ * All pointers are device pointers, f32; *d_count is the (global) number of samples the losses average over.
+ *
+ * fjsp_ppo_actor_loss: logits f32[n][n_actions] of the new policy, d_actions f32[n] (flat action index),
+ * d_old_log_prob / d_advantages f32[n] -> *d_loss = -sum(min(A r, A clip(r, 1 - eps, 1 + eps))) / count with
+ * r = exp(log_softmax(logits)[action]) / (exp(old) + 1e-8) (:325-352), and d_dlogits = d loss / d logits with
+ * autograd's conventions (minimum halves ties, clamp passes the gradient on the closed interval).
+ * d_partial: f32 scratch of fjsp_ppo_partials(n) entries.
+ * fjsp_ppo_critic_loss: *d_loss = sum((value - returns)^2) / count (F.mse_loss, :317-318), d_dvalue = its gradient.
+ * fjsp_relu_bwd_bias: d_dh f32[n][width] <- d_dh * (d_h > 0) in place (d_h == NULL: no mask) and d_bias_grad
+ * f32[width] = its column sums, through d_partial f32[n_partial_rows][width] (two-stage, deterministic).
+ * fjsp_adam_clip_step: clip_grad_norm_(max_norm; <= 0: none) followed by one Adam step (torch.optim.Adam, no weight
+ * decay) over flat buffers of n parameters; *d_step is the step count kept on the device (f32), d_scratch64 f32[64]. */
+int fjsp_ppo_partials(int32_t n);
+int fjsp_ppo_actor_loss(const float *d_logits, const float *d_actions, const float *d_old_log_prob, const float *d_advantages, int32_t n,
+                        int32_t n_actions, float clip_epsilon, const float *d_count, float *d_dlogits, float *d_partial, float *d_loss,
+                        void *stream);
+int fjsp_ppo_critic_loss(const float *d_value, const float *d_returns, int32_t n, const float *d_count, float *d_dvalue, float *d_partial,
+                         float *d_loss, void *stream);
+int fjsp_relu_bwd_bias(float *d_dh, const float *d_h, int32_t n, int32_t width, float *d_partial, int32_t n_partial_rows, float *d_bias_grad,
+                       void *stream);
+int fjsp_adam_clip_step(float *d_params, const float *d_grads, float *d_exp_avg, float *d_exp_avg_sq, int32_t n, float max_norm, float lr,
+                        float beta1, float beta2, float eps, float *d_step, float *d_scratch64, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,3 +449,37 @@ def test_ppo_rounds_with_the_fused_policy_rollout(torch_gpu):
         tot = (agent.memory.rewards[:len(agent.memory)].double() * valid.double()).sum(0)
         assert torch.equal(-tot.long(), r["delay_time_sum"])
     assert any(not torch.equal(b, p) for b, p in zip(before, agent.learner.actor_new.parameters()))
+
+
+def test_fused_ppo_learning_matches_autograd(torch_gpu):
+    """agents/fused_mlp.py (library GEMMs + csrc/fjsp_ppo.hip: loss and its gradient, ReLU backward + bias gradient,
+    clip + Adam on flat buffers) against the autograd path of PPOLearner on the same 40 000 samples and weights:
+    one learning iteration (tight: f32 reassociation only) and a full 10-iteration round."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import PPOLearner
+    n, S, A = 40000, 20, 30
+    g = torch.Generator(device="cuda").manual_seed(5)
+    states = torch.randn(n, S, device="cuda", generator=g)
+    actions = torch.randint(0, A, (n,), device="cuda", generator=g)
+    old_lp = -torch.rand(n, device="cuda", generator=g) * 4 - 0.5
+    returns = torch.randn(n, device="cuda", generator=g)
+    valid = torch.ones(n, device="cuda")
+    for iters, rtol, atol in ((1, 2e-4, 2e-6), (10, 2e-2, 2e-4)):
+        hyper = {"learning_iterations_per_round_critic": iters, "learning_iterations_per_round_actor": iters}
+        ref = PPOLearner(S, A, 128, 2, 2, device="cuda", seed=9, hyper=hyper); ref.fused_learn = False
+        fus = PPOLearner(S, A, 128, 2, 2, device="cuda", seed=9, hyper=hyper)
+        for pr, pf in zip(list(ref.actor_new.parameters()) + list(ref.critic.parameters()),
+                          list(fus.actor_new.parameters()) + list(fus.critic.parameters())):
+            assert torch.equal(pr, pf)
+        lr_ = ref.learn(states, actions, old_lp, returns, valid)
+        lf_ = fus.learn(states, actions, old_lp, returns, valid)
+        assert fus._use_fused and not ref._use_fused
+        np.testing.assert_allclose(lf_, lr_, rtol=max(rtol, 1e-4), atol=1e-5)
+        for name, nr, nf in (("actor", ref.actor_new, fus.actor_new), ("critic", ref.critic, fus.critic), ("actor_old", ref.actor_old, fus.actor_old)):
+            for pr, pf in zip(nr.parameters(), nf.parameters()):
+                np.testing.assert_allclose(pf.detach().cpu().numpy(), pr.detach().cpu().numpy(), rtol=rtol, atol=atol,
+                                           err_msg="%s after %d iteration(s)" % (name, iters))
+    # the parameters live in ONE flat buffer (the all-reduce bucket), the module still owns them
+    actor_tr, _ = fus._fused_nets()
+    assert actor_tr.flat.numel() == sum(p.numel() for p in fus.actor_new.parameters())
+    assert fus.actor_new.layers[0].weight.data_ptr() == actor_tr.flat.data_ptr()

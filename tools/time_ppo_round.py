@@ -9,7 +9,8 @@ from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO import MPPPO as M
 N = 4096
 insts = fi.InstanceSet(N).generate_range(1000, fi.bench_10x5_params()).solve_fluid()
 env = BatchedSOFJSSP(insts, rng_seed=7)
-agent = M.PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph='--eager' not in sys.argv, fused_sampling='--eager' not in sys.argv)
+agent = M.PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph='--eager' not in sys.argv, fused_sampling='--eager' not in sys.argv,
+              fused_rollout='--eager' not in sys.argv and '--per-step-rollout' not in sys.argv)
 agent.run_one_policy_network()
 orig_learn = agent.learner.learn
 t_learn = [0.0]
