@@ -173,7 +173,7 @@ class DDQN(Base_Agent, Config):
         states, actions, rewards, next_states, dones = self.memory.sample() if experiences is None else experiences
         loss = ddqn_loss(self.q_network_local, self.q_network_target, states, actions, rewards, next_states, dones,
                          hp["discount_rate"])
-        self.q_network_optimizer.zero_grad()
+        self.bucket.zero_()                          # (gradients live in the all-reduce bucket)
         (loss / fdist.world_size()).backward()
         self.bucket.all_reduce()
         torch.nn.utils.clip_grad_norm_(self.q_network_local.parameters(), hp["gradient_clipping_norm"])

@@ -219,7 +219,7 @@ class DA3C(Base_Agent, Config):
         c_loss, t_loss, m_loss = a2c_losses(lp_t, lp_m, values, G, valid)
         w = fdist.world_size()
         for net, opt, bucket, loss in zip(self.nets, self.optimizers, self.buckets, (t_loss, m_loss, c_loss)):
-            opt.zero_grad()
+            bucket.zero_()                            # (gradients live in the all-reduce bucket)
             (loss / w).backward()
             bucket.all_reduce()
             torch.nn.utils.clip_grad_norm_(net.parameters(), self.hp["gradient_clipping_norm"])

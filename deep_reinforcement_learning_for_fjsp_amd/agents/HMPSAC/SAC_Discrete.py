@@ -245,7 +245,10 @@ class SAC_Discrete(Base_Agent, Config):
         return False
 
     def _optimise(self, optimizer, network, loss):
-        optimizer.zero_grad()
+        if network is not None:
+            self.buckets[network].zero_()             # (gradients live in the all-reduce bucket)
+        else:
+            optimizer.zero_grad()
         (loss / fdist.world_size()).backward()
         if network is not None:
             self.buckets[network].all_reduce()

@@ -201,7 +201,7 @@ class PPOLearner(object):
             critic_out = self.critic(states).squeeze(1)
             c_loss = (((critic_out - returns) ** 2) * m).sum() / count                 # F.mse_loss, :318
             if self.train_critic:
-                self.critic_optimizer.zero_grad()
+                self.critic_bucket.zero_()           # (gradients live in the all-reduce bucket)
                 c_loss.backward()
                 self.critic_bucket.all_reduce()
                 torch.nn.utils.clip_grad_norm_(self.critic.parameters(), hp["gradient_clipping_norm"])
@@ -209,7 +209,7 @@ class PPOLearner(object):
             new_log_prob = self.actor_new.log_prob(states, actions)
             terms = actor_loss_terms(new_log_prob, old_log_prob, advantages, hp["clip_epsilon"])
             a_loss = -(terms * m).sum() / count                                         # -torch.mean(...), :351
-            self.actor_optimizer.zero_grad()
+            self.actor_bucket.zero_()
             a_loss.backward()
             self.actor_bucket.all_reduce()
             torch.nn.utils.clip_grad_norm_(self.actor_new.parameters(), hp["gradient_clipping_norm"])

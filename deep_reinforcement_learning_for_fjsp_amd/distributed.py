@@ -64,33 +64,50 @@ def all_reduce_scalar_sum(x):
 
 
 class FlatGradBucket(object):
-    """One contiguous f32 buffer holding all gradients of a network; `all_reduce()` copies the
-    gradients in, issues ONE all-reduce (sum) and copies the result back."""
+    """One contiguous f32 buffer that IS the gradient storage of a network: `zero_()` (in place of
+    optimizer.zero_grad()) clears it and makes every parameter's `.grad` a view of its slice, so backward accumulates
+    straight into the bucket and `all_reduce()` is ONE collective with no packing or unpacking.  A
+    caller that still lets the optimiser drop the gradients (zero_grad(set_to_none=True)) gets the copying fallback."""
 
     def __init__(self, parameters):
         self.params = [p for p in parameters if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.views = None
+
+    def _ensure(self):
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+            self.views, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                self.views.append(self.flat[off:off + n].view_as(p))
+                off += n
+
+    def zero_(self):
+        self._ensure()
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def _in_place(self):
+        return self.views is not None and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 
     def all_reduce(self):
         if not is_distributed():
             return
-        dev = self.params[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            n = p.numel()
+        self._ensure()
+        if self._in_place():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            return
+        for p, v in zip(self.params, self.views):          # fallback: gradients allocated by autograd, copied in and out
             if p.grad is None:
-                self.flat[off:off + n].zero_()
+                v.zero_()
             else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+                v.copy_(p.grad)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        off = 0
-        for p in self.params:
-            n = p.numel()
+        for p, v in zip(self.params, self.views):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-            p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+            p.grad.copy_(v)
