@@ -100,6 +100,8 @@ struct Layout {
     uint32_t e_tsum;    // f64[KP]
     uint32_t e_col;     // f64[KP][MP][2]
     uint32_t e_dyn;     // MO_DFJSP batches only: DynScalars, then i32[MP] time_end of the machine's last task (-1 = none)
+    uint32_t e_stats;   // u32[KP][16] update_parameter's per-(r, j) statistics as the last kernel left them (batches with several
+                        // jobs per kind only: there they are a walk over the kind's jobs, too long to redo at every step entry)
     uint32_t e_lpq;     // u16[2][KP] LP inputs of the pending arrival: Q[k], n_now[k]; then i16[2] stashed (k, m) of the step
 };
 

@@ -294,6 +294,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             L.e_col = take(MP * KP * 16, 16); L.e_lpq = take(KP * 4 + 8, 4);
         }
         if (dyn) L.e_dyn = take(sizeof(DynScalars) + MP * 4, 8);
+        L.e_stats = b.single_job ? 0u : take(KP * 64, 64);
         L.e_stride = (uint32_t)((o + 255) / 256 * 256);
     }
     std::vector<unsigned char> islab(NI * L.i_stride, 0);

@@ -243,7 +243,7 @@ struct W {
     // makes the compiler spill it to scratch and re-load fields through memory)
     int KP, MP, JP, n_obs, n_static, state_size;
     bool single_job;         // DevBatch::single_job
-    uint32_t e_jst, e_tend, e_mjob, e_un, e_dyn;
+    uint32_t e_jst, e_tend, e_mjob, e_un, e_dyn, e_stats;
     const double *sstate;
     double fluid_completed_time;
     int env, inst, lane;
@@ -256,7 +256,8 @@ struct W {
     long long tard_done, delay_sum;
     uint64_t env_seed;
     int t_arr, next_order, pending, n_orders;      // order arrivals (multi-order batches)
-    int obs_stale;                                 // obs_prev_l is not v(t-1) (EnvScalars::obs_stale)
+    int obs_stale;                                 // obs_prev_l is not v(t-1) (EnvScalars::obs_stale bit 0)
+    int stats_ok;                                  // the record's e_stats are current (EnvScalars::obs_stale bit 1 clear)
     long long energy, energy_last;                 // MO_DFJSP: energy_consumption(_last)
     const unsigned char *ir;
     // lane = operation type
@@ -299,11 +300,11 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, boo
 // instance header), so they are in flight together: one memory round trip.
 template <int KC, int V>
 __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
-                                         bool load_state) {
+                                         bool load_state, bool want_stats = false) {
     w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
     w.single_job = !is_mord_v<V> && b->single_job != 0;
-    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn;
+    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = b->n_inst == b->N ? env : env % b->n_inst;     // (one instance per environment: no division)
@@ -346,6 +347,17 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
             w.q0[c] = 0;                     // = jobs of the kind, set below
         }
     }
+    // update_parameter's statistics as the previous kernel left them (batches with several jobs per kind)
+    uint4 st4[KC][4];
+    const bool load_stats = load_state && want_stats && !w.single_job;      // (kernels that recompute them anyway pass want_stats = false)
+    if (load_stats) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(er + L.e_stats) + (size_t)(c * kWave + w.lane) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4[c][q] = sp[q];
+        }
+    }
     const int jcap = b->jcap;
     int32_t due0 = 0;
     if (w.lane < jcap) due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
@@ -379,7 +391,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.pw_i = reinterpret_cast<const uint16_t *>(ir + (V == kDyn ? L.i_pw : L.i_p));
     w.col_i = reinterpret_cast<const double *>(is_mord_v<V> ? er + L.e_col : ir + L.i_col);
     w.ir = ir;
-    w.t_arr = 0; w.next_order = 1; w.pending = 0; w.obs_stale = 0;
+    w.t_arr = 0; w.next_order = 1; w.pending = 0; w.obs_stale = 0; w.stats_ok = 0;
     w.env_seed = b->rng_seed + (uint64_t)env * 1000003ULL;
     w.sstate = reinterpret_cast<const double *>(ir + L.i_ss);
     w.fluid_completed_time = w.sstate[7];
@@ -404,7 +416,8 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.completion = uni(sc.completion); w.completion_last = uni(sc.completion_last);
     w.tard_done = sc.tard_done; w.delay_sum = sc.delay_sum;
     w.t_arr = uni(sc.t_arr); w.next_order = uni((int)sc.next_order); w.pending = uni((int)sc.pending);
-    w.obs_stale = uni((int)sc.obs_stale);
+    w.obs_stale = uni((int)sc.obs_stale) & 1;
+    w.stats_ok = !(uni((int)sc.obs_stale) & 2);
     w.obs_prev_l = obs0;
     w.tend_m = w.lane < w.M ? tend0 : 0;
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
@@ -413,11 +426,22 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         const double *src = reinterpret_cast<const double *>(er + L.e_un);
         for (int i = w.lane; i < w.K * MP; i += kWave) w.unp[i] = src[i];
     }
+    if (load_stats) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            w.nun[c] = (int)st4[c][0].x; w.cnt_a[c] = (int)st4[c][0].y; w.cnt_e[c] = (int)st4[c][0].z; w.max_a[c] = (int)st4[c][0].w;
+            w.fifo_cnt[c] = (int)st4[c][1].x; w.head_job[c] = (int)st4[c][1].y; w.due_min[c] = (int)st4[c][1].z; w.tard[c] = (int)st4[c][1].w;
+            w.max_e[c] = __hiloint2double((int)st4[c][2].y, (int)st4[c][2].x); w.sum_e[c] = __hiloint2double((int)st4[c][2].w, (int)st4[c][2].z);
+            if (is_mord_v<V>) w.tot[c] = (int)st4[c][3].x;
+        }
+    }
     wave_sync();
 }
 
+// store_stats: also leave update_parameter's statistics in the record (what step_kernel starts from in batches with
+// several jobs per kind); kernels that keep them to themselves mark the record's copy invalid instead.
 template <int KC, int V>
-__device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
+__device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds, bool store_stats = true) {
     unsigned char *er = w.er;
     wave_sync();
     if (w.lane == 0) {
@@ -426,7 +450,8 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
         es->status = w.status; es->seq_ctr = w.seq_ctr; es->rng_calls = w.rng_calls; es->busy = w.busy;
         es->completion = w.completion; es->completion_last = w.completion_last;
         es->tard_done = w.tard_done; es->delay_sum = w.delay_sum;
-        es->t_arr = w.t_arr; es->next_order = (int16_t)w.next_order; es->pending = (int8_t)w.pending; es->obs_stale = (int8_t)w.obs_stale;
+        es->t_arr = w.t_arr; es->next_order = (int16_t)w.next_order; es->pending = (int8_t)w.pending;
+        es->obs_stale = (int8_t)((w.obs_stale & 1) | ((store_stats || w.single_job) ? 0 : 2));
     }
     if (w.lane < 10) reinterpret_cast<EnvScalars *>(er)->obs_prev[w.lane] = w.obs_prev_l;
     if (w.lane < w.M) {
@@ -440,6 +465,17 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds) {
         if (w.lane < w.M) reinterpret_cast<int32_t *>(er + w.e_dyn + sizeof(DynScalars))[w.lane] = w.tlast_m;
     }
     for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + w.e_jst)[n] = w.jstL[n];
+    if (!w.single_job && store_stats) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            uint4 *sp = reinterpret_cast<uint4 *>(er + w.e_stats) + (size_t)(c * kWave + w.lane) * 4;
+            sp[0] = make_uint4((uint32_t)w.nun[c], (uint32_t)w.cnt_a[c], (uint32_t)w.cnt_e[c], (uint32_t)w.max_a[c]);
+            sp[1] = make_uint4((uint32_t)w.fifo_cnt[c], (uint32_t)w.head_job[c], (uint32_t)w.due_min[c], (uint32_t)w.tard[c]);
+            sp[2] = make_uint4((uint32_t)__double2loint(w.max_e[c]), (uint32_t)__double2hiint(w.max_e[c]),
+                               (uint32_t)__double2loint(w.sum_e[c]), (uint32_t)__double2hiint(w.sum_e[c]));
+            sp[3] = make_uint4((uint32_t)w.tot[c], 0u, 0u, 0u);
+        }
+    }
     if (un_lds) {
         double *dst = reinterpret_cast<double *>(er + w.e_un);
         for (int i = w.lane; i < w.K * w.MP; i += kWave) dst[i] = w.unp[i];
@@ -1544,7 +1580,7 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
 // environment (finished episode, invalid rule), so nothing below returns between the first barrier and the last.
 template <int KC, int V>
 // (four chunks of per-lane operation state do not fit 128 VGPRs: K > 128 runs at half the occupancy instead of spilling)
-__global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
+__global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
                                                       double *state_out, double *reward_out, uint8_t *done_out,
                                                       int16_t *trace_km) {
     constexpr bool SHARED = FJSP_SHARED_TAIL && !is_mord_v<V>;
@@ -1568,7 +1604,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
         a0 = uni((int)actions[(size_t)env * 2]); a1 = uni((int)actions[(size_t)env * 2 + 1]);
     }
     const uint32_t lds_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
-    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_stride, false, true);
+    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_stride, false, true, true);
     if (env_raw >= b.N) return;                       // (a finished wave no longer counts at the workgroup's barriers)
     STAMP(w, 0);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 4
@@ -1584,8 +1620,8 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
         } else {
             init_episode<KC, V>(w, &b, nullptr, true);
         }
-    } else {
-        compute_params<KC, V>(w);
+    } else if (w.single_job || !w.stats_ok) {
+        compute_params<KC, V>(w);            // a handful of selects; batches with longer lists found the statistics in the record
     }
     STAMP(w, 1);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 3
@@ -1613,7 +1649,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void step_kernel(DevBatch b, 
             const uint32_t *src = reinterpret_cast<const uint32_t *>(w.er + b.L.e_lpq);     // u16[2][KP] as KP words
             uint32_t *dst = reinterpret_cast<uint32_t *>(b.lp_in + (size_t)slot * 2 * b.KP);
             for (int i = w.lane; i < b.KP; i += kWave) dst[i] = src[i];
-            store_dynamic<KC, V>(w, false);
+            store_dynamic<KC, V>(w, false, false);        // (statistics are stale until arrival_kernel finishes the step)
             return;
         }
     } else {
@@ -1781,7 +1817,7 @@ __global__ __launch_bounds__(1024) void rollout_policy_kernel(DevBatch b, ActorP
             io.o_flat[row] = (float)action; io.o_logp[row] = logp;
         }
     }
-    store_dynamic<KC, V>(w, false);
+    store_dynamic<KC, V>(w, false, false);
 }
 
 // Multi-order: finish the step of every env parked at an order arrival.  The host service has solved the
