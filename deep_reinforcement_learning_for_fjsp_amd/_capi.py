@@ -53,6 +53,10 @@ SIGNATURES = {
     "fjsp_env_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fjsp_env_step": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "fjsp_env_step_traced": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_env_step_async": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_env_arrivals_flush": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_env_parked": (_i64, [_vp]),
+    "fjsp_env_lp_cache_hits": (_i64, [_vp]),
     "fjsp_env_rollout": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "fjsp_env_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fjsp_env_machine_time_end": (C.c_int, [_vp, _vp, _i32, _vp]),

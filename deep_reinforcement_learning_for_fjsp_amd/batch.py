@@ -191,6 +191,37 @@ class EnvBatch(object):
             check(rc)
         return state_out, reward_out, done_out
 
+    def step_async(self, actions, autoreset=False, mo=None):
+        """fjsp_env_step_async: like step(), but envs that reach an order arrival park (their fluid LP is solved by
+        host threads in the background) while the others keep stepping.  Returns (state, reward, done, ready):
+        ready[i] = 1 where this call completed a step of env i; a parked env ignored its action -- present it again.
+        Call flush_arrivals() before read() / reset() / step() / rollout()."""
+        actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
+        mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
+        if getattr(self, "ready", None) is None:
+            self.ready = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+        check(self._lib.fjsp_env_step_async(self._h, _ptr(actions), _ptr(mo), 1 if autoreset else 0, self._p_state, self._p_reward,
+                                            self._p_done, _ptr(self.ready), self._stream()))
+        self._last_mo = mo
+        return self.state, self.reward, self.done, self.ready
+
+    def flush_arrivals(self, mo=None):
+        """Wait for every parked env and finish its step (rows of state / reward / done, ready = 1)."""
+        mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device) if mo is not None else getattr(self, "_last_mo", None)
+        if getattr(self, "ready", None) is None:
+            self.ready = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+        check(self._lib.fjsp_env_arrivals_flush(self._h, _ptr(mo), self._p_state, self._p_reward, self._p_done, _ptr(self.ready),
+                                                self._stream()))
+        return self.state, self.reward, self.done, self.ready
+
+    @property
+    def lp_cache_hits(self):
+        return int(self._lib.fjsp_env_lp_cache_hits(self._h))
+
+    @property
+    def parked(self):
+        return int(self._lib.fjsp_env_parked(self._h))
+
     def rollout(self, actions, trace=True, rewards=True, mo=None, state=True):
         """T fused steps in one launch. actions: uint8[T, N, 2]. Returns (trace_km i16[T,N,2], reward f64[T,N], state).
         state=False: no final state (the fused kernel then skips the observation)."""

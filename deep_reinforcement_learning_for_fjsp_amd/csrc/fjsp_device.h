@@ -132,15 +132,17 @@ __host__ __device__ inline T *env_ptr(const DevBatch &b, int env, uint32_t off) 
 // kernel launchers (fjsp_kernels.hip); all asynchronous on `st`, 0 = launched
 int launch_fluid_tables(const DevBatch &b, hipStream_t st);
 int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStream_t st);
+// ready (nullable, multi-order batches): asynchronous arrival service, see fjsp_env_step_async
 int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
-                uint8_t *done, int16_t *trace_km, hipStream_t st);
+                uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready = nullptr);
 size_t rollout_lds_bytes(const DevBatch &b);
 size_t step_lds_bytes(const DevBatch &b);     // dynamic LDS of one reset / step / arrival workgroup
 int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                    double *state_last, hipStream_t st);
 // multi-order: resume the envs whose pending LP has been solved (x in e_xin)
-int launch_arrival(const DevBatch &b, const double *mo, int n_pending, double *state, double *reward, uint8_t *done, int16_t *trace_km,
-                   hipStream_t st);
+// ids u32[n_pending] / x_list f64[n_pending][KP][MP]: the parked envs and their LP solutions (device)
+int launch_arrival(const DevBatch &b, const double *mo, int n_pending, const uint32_t *ids, const double *x_list, double *state,
+                   double *reward, uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready = nullptr, bool mark_resumed = false);
 // policy inside the launch (fjsp_policy.h)
 struct ActorParams;
 struct PolicyRolloutIO;

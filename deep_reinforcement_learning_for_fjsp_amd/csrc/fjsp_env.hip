@@ -3,6 +3,9 @@
 // of environments and launches the kernels of fjsp_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <deque>
+
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -12,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/fjsp_amd.h"
@@ -21,6 +25,34 @@
 #include "fjsp_policy.h"
 
 using namespace fjsp;
+
+// Order-arrival LPs repeat: environments that play the same instance and reach an arrival in the same situation (the
+// same unprocessed / waiting counts per operation type -- always the case when the shop had run empty and the clock
+// jumped to the arrival, SO_FJSSP.py:228-231) pose the same LP.  The LP is a pure function of (instance, Q, n_now), so
+// its solution is remembered (same bits as a fresh solve).
+struct LpCache {
+    std::mutex mu;
+    std::unordered_map<std::string, std::vector<double>> map;
+    int64_t hits = 0, misses = 0;
+    static std::string key(int inst, const uint16_t *lpq, size_t KP, int K) {
+        std::string k(sizeof(int) + (size_t)K * 4, '\0');
+        std::memcpy(&k[0], &inst, sizeof(int));
+        std::memcpy(&k[sizeof(int)], lpq, (size_t)K * 2);
+        std::memcpy(&k[sizeof(int) + (size_t)K * 2], lpq + KP, (size_t)K * 2);
+        return k;
+    }
+    bool find(const std::string &k, std::vector<double> &x) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = map.find(k);
+        if (it == map.end()) { ++misses; return false; }
+        ++hits; x = it->second;
+        return true;
+    }
+    void put(const std::string &k, const std::vector<double> &x) {
+        std::lock_guard<std::mutex> g(mu);
+        if (map.size() < 200000) map.emplace(k, x);
+    }
+};
 
 struct fjsp_env {
     DevBatch b{};
@@ -37,6 +69,17 @@ struct fjsp_env {
     uint32_t *h_pending = nullptr;
     uint16_t *h_lp_in = nullptr;
     double *h_lp_x = nullptr;
+    // asynchronous arrival service (fjsp_env_step_async): a ring of batches of parked envs on their way through
+    // D2H copy -> host LPs (dispatcher thread) -> upload -> arrival_kernel, while the other envs keep stepping
+    struct AsyncBatch *ring = nullptr;
+    int ring_n = 0, ring_next = 0;
+    struct LpWorkers *workers = nullptr;
+    hipStream_t copy_stream = nullptr;  // the parked envs' ids / LP inputs leave on their own stream: the next step launch does not wait for them
+    hipEvent_t ev_step = nullptr;
+    LpCache lp_cache;
+    uint32_t *d_resume_ids = nullptr;   // [N] device list handed to arrival_kernel
+    double *d_resume_x = nullptr;       // [N][KP][MP]
+    int64_t async_parked = 0;           // envs currently parked (host view)
     bool failed = false;        // the arrival service failed mid-step: parked envs are in limbo, the handle refuses further steps
     int lp_threads = 0;         // 0 = default (min(host cores, 16))
     int64_t lp_solves = 0;      // order-arrival LPs solved so far
@@ -92,6 +135,63 @@ struct LpPool {
         drain();
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return active == 0; });
+    }
+};
+
+// One launch's parked environments on their way through the asynchronous arrival service.
+struct AsyncBatch {
+    enum State { FREE, HEAD_COPY, TAIL_COPY, SOLVING, SOLVED, UPLOADING };
+    uint32_t *d_count = nullptr;      // device staging the parking waves write: [0] = count, [1 + slot] = env id
+    uint16_t *d_lp_in = nullptr;      //                                         [slot][2][KP] LP inputs (Q, n_now)
+    uint32_t *h_ids = nullptr;        // pinned mirrors
+    uint16_t *h_lp_in = nullptr;
+    double *h_x = nullptr;            // pinned [slot][KP][MP] solutions
+    hipEvent_t ev_head = nullptr, ev_tail = nullptr, ev_up = nullptr;
+    State state = FREE;
+    uint32_t n = 0, cap = 0;          // parked envs of this batch; capacity of the pinned mirrors (grown on demand)
+    std::atomic<int> solved{0};       // 1 = every LP solved, -1 = a solve failed
+    std::atomic<int> left{0}, bad{0};
+    std::mutex err_mu;
+    std::string err;
+};
+
+// Worker threads of the asynchronous service: ONE queue of single LPs across all batches in flight, so that the
+// threads stay busy whatever the batch sizes are; a batch is solved when its last LP is.
+struct LpWorkers {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<AsyncBatch *, uint32_t>> tasks;
+    std::function<bool(AsyncBatch *, uint32_t)> solve;      // false: the LP failed (message left in the batch)
+    bool stop = false;
+    LpWorkers(int n, std::function<bool(AsyncBatch *, uint32_t)> f) : solve(std::move(f)) {
+        for (int t = 0; t < n; ++t) th.emplace_back([this] { loop(); });
+    }
+    ~LpWorkers() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void submit(AsyncBatch *a) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (uint32_t q = 0; q < a->n; ++q) tasks.emplace_back(a, q);
+        }
+        cv.notify_all();
+    }
+    void loop() {
+        for (;;) {
+            std::pair<AsyncBatch *, uint32_t> t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !tasks.empty(); });
+                if (tasks.empty()) return;              // (stop: drain first)
+                t = tasks.front();
+                tasks.pop_front();
+            }
+            if (!solve(t.first, t.second)) t.first->bad.store(1);
+            if (t.first->left.fetch_sub(1) == 1) t.first->solved.store(t.first->bad.load() ? -1 : 1);
+        }
     }
 };
 
@@ -479,6 +579,22 @@ void fjsp_env_destroy(fjsp_env *e) {
         if (e->h_lp_in) (void)hipHostFree(e->h_lp_in);
         if (e->h_lp_x) (void)hipHostFree(e->h_lp_x);
     }
+    delete e->workers;               // (joins: LPs still queued are solved first)
+    if (e->ring) {
+        DeviceGuard guard(e->device);
+        for (int q = 0; q < e->ring_n; ++q) {
+            AsyncBatch &a = e->ring[q];
+            if (a.d_count) (void)hipFree(a.d_count);
+            if (a.d_lp_in) (void)hipFree(a.d_lp_in);
+            if (a.h_ids) (void)hipHostFree(a.h_ids);
+            if (a.h_lp_in) (void)hipHostFree(a.h_lp_in);
+            if (a.h_x) (void)hipHostFree(a.h_x);
+            for (hipEvent_t ev : {a.ev_head, a.ev_tail, a.ev_up}) if (ev) (void)hipEventDestroy(ev);
+        }
+        if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+        if (e->ev_step) (void)hipEventDestroy(e->ev_step);
+        delete[] e->ring;
+    }
     delete e->pool;
     delete e;
 }
@@ -541,10 +657,14 @@ int service_arrivals_impl(fjsp_env *e, const double *d_mo, double *d_state, doub
         for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
         std::vector<double> xk((size_t)in.K * in.M, 0.0);
         double obj = 0.0;
-        if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) {
-            std::lock_guard<std::mutex> g(err_mu);
-            if (fail.fetch_add(1) == 0) err = fjsp_last_error();     // thread-local message of this worker
-            return;
+        const std::string ck = LpCache::key(env % b.n_inst, lpq, KP, in.K);
+        if (!e->lp_cache.find(ck, xk)) {
+            if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (fail.fetch_add(1) == 0) err = fjsp_last_error();     // thread-local message of this worker
+                return;
+            }
+            e->lp_cache.put(ck, xk);
         }
         double *xin = e->h_lp_x + (size_t)q * KP * MP;
         std::fill(xin, xin + KP * MP, 0.0);
@@ -562,15 +682,231 @@ int service_arrivals_impl(fjsp_env *e, const double *d_mo, double *d_state, doub
     }
     if (fail.load()) { set_error(err); return FJSP_E_LP; }
     HIP_TRY(hipMemcpyAsync(b.lp_x, e->h_lp_x, (size_t)n * KP * MP * 8, hipMemcpyHostToDevice, st));
-    if (launch_arrival(b, d_mo, (int)n, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
+    if (launch_arrival(b, d_mo, (int)n, b.pending_count + 1, b.lp_x, d_state, d_reward, d_done, d_trace, st) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
     HIP_TRY(hipMemsetAsync(b.pending_count, 0, 4, st));
     e->lp_solves += n;
     return FJSP_OK;
 }
 }  // namespace
 
+// ------------------------------------------------------------------ asynchronous arrival service
+namespace {
+constexpr int kAsyncRing = 32;         // batches in flight: a parked env waits for its LP (0.05 .. 0.8 ms) while calls come every ~0.03 ms
+constexpr uint32_t kAsyncHead = 64;    // parked envs whose ids + LP inputs travel with the count (more: a second copy)
+
+// pinned mirrors of a batch for `need` parked envs (grow-only: a typical launch parks a few dozen envs, a launch right
+// after a synchronised reset can park all of them)
+int async_reserve(fjsp_env *e, AsyncBatch &a, uint32_t need) {
+    if (need <= a.cap) return FJSP_OK;
+    const DevBatch &b = e->b;
+    const size_t KP = (size_t)b.KP, MP = (size_t)b.MP;
+    uint32_t cap = std::max<uint32_t>(kAsyncHead, a.cap);
+    while (cap < need) cap *= 2;
+    cap = std::min<uint32_t>(cap, (uint32_t)b.N);
+    uint32_t *ids = nullptr; uint16_t *in = nullptr; double *x = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ids), ((size_t)cap + 1) * 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&in), (size_t)cap * 2 * KP * 2, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&x), (size_t)cap * KP * MP * 8, hipHostMallocDefault));
+    if (a.h_ids) {           // keep what the head copy already delivered
+        std::memcpy(ids, a.h_ids, ((size_t)std::min(a.cap, cap) + 1) * 4);
+        std::memcpy(in, a.h_lp_in, (size_t)std::min(a.cap, cap) * 2 * KP * 2);
+        (void)hipHostFree(a.h_ids); (void)hipHostFree(a.h_lp_in); (void)hipHostFree(a.h_x);
+    }
+    a.h_ids = ids; a.h_lp_in = in; a.h_x = x; a.cap = cap;
+    return FJSP_OK;
+}
+
+bool async_solve_one(fjsp_env *e, AsyncBatch *a, uint32_t q) {
+    const DevBatch &b = e->b;
+    const size_t KP = (size_t)b.KP, MP = (size_t)b.MP;
+    const int env = (int)a->h_ids[1 + q];
+    const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
+    const uint16_t *lpq = a->h_lp_in + (size_t)q * 2 * KP;
+    std::vector<int> Q(in.K), now(in.K);
+    for (int k = 0; k < in.K; ++k) { Q[k] = lpq[(size_t)k]; now[k] = lpq[KP + (size_t)k]; }
+    std::vector<double> xk((size_t)in.K * in.M, 0.0);
+    double obj = 0.0;
+    const std::string ck = LpCache::key(env % b.n_inst, lpq, KP, in.K);
+    if (!e->lp_cache.find(ck, xk)) {
+        if (solve_fluid_lp(in.R, in.M, in.Jr.data(), in.p.data(), Q.data(), now.data(), xk.data(), &obj) != 0) {
+            std::lock_guard<std::mutex> g(a->err_mu);
+            a->err = fjsp_last_error();              // (thread-local message of this worker)
+            return false;
+        }
+        e->lp_cache.put(ck, xk);
+    }
+    double *xin = a->h_x + (size_t)q * KP * MP;
+    std::fill(xin, xin + KP * MP, 0.0);
+    for (int k = 0; k < in.K; ++k)
+        for (int m = 0; m < in.M; ++m) xin[(size_t)k * MP + m] = xk[(size_t)k * in.M + m];
+    return true;
+}
+
+int async_setup(fjsp_env *e) {
+    if (e->ring) return FJSP_OK;
+    const DevBatch &b = e->b;
+    const size_t N = (size_t)b.N, KP = (size_t)b.KP, MP = (size_t)b.MP;
+    e->ring = new AsyncBatch[kAsyncRing];
+    e->ring_n = kAsyncRing;
+    for (int q = 0; q < kAsyncRing; ++q) {
+        AsyncBatch &a = e->ring[q];
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.d_count), (N + 1) * 4));
+        HIP_TRY(hipMemset(a.d_count, 0, (N + 1) * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.d_lp_in), N * 2 * KP * 2));
+        const int rc = async_reserve(e, a, kAsyncHead);
+        if (rc != FJSP_OK) return rc;
+        HIP_TRY(hipEventCreateWithFlags(&a.ev_head, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&a.ev_tail, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&a.ev_up, hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_step, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_resume_ids), N * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_resume_x), N * KP * MP * 8));
+    e->allocs.push_back(e->d_resume_ids);
+    e->allocs.push_back(e->d_resume_x);
+    // the threads the box gives (16 per GPU); more only oversubscribes a latency-critical wait
+    int n_threads = e->lp_threads > 0 ? std::min(e->lp_threads, (int)std::thread::hardware_concurrency())
+                                      : std::min((int)std::thread::hardware_concurrency(), 16);
+    if (n_threads <= 0) n_threads = 1;
+    e->workers = new LpWorkers(n_threads, [e](AsyncBatch *a, uint32_t q) { return async_solve_one(e, a, q); });
+    return FJSP_OK;
+}
+
+bool async_idle(const fjsp_env *e) {
+    if (!e->ring) return true;
+    for (int q = 0; q < e->ring_n; ++q) if (e->ring[q].state != AsyncBatch::FREE) return false;
+    return true;
+}
+
+// hand a batch's LPs to the worker threads
+void async_submit(fjsp_env *e, AsyncBatch *a) {
+    a->solved.store(0); a->bad.store(0); a->left.store((int)a->n);
+    a->state = AsyncBatch::SOLVING;
+    e->workers->submit(a);
+}
+
+// Advance every batch as far as it can go without waiting (block: with waiting, until the ring is empty).  Batches
+// whose LPs are solved are uploaded and finished by arrival_kernel, which writes their outputs and ready = 1.
+int async_progress(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, uint8_t *d_ready, hipStream_t st,
+                   bool block, bool mark_resumed) {
+    const DevBatch &b = e->b;
+    const size_t KP = (size_t)b.KP, MP = (size_t)b.MP;
+    for (;;) {
+        bool busy = false;
+        for (int off = 0; off < e->ring_n; ++off) {
+            AsyncBatch &a = e->ring[(e->ring_next + off) % e->ring_n];       // oldest first
+            if (a.state == AsyncBatch::HEAD_COPY) {
+                hipError_t q = block ? hipEventSynchronize(a.ev_head) : hipEventQuery(a.ev_head);
+                if (q == hipErrorNotReady) { busy = true; continue; }
+                HIP_TRY(q);
+                a.n = a.h_ids[0];
+                if (a.n > (uint32_t)b.N) a.n = (uint32_t)b.N;
+                e->async_parked += a.n;
+                if (a.n == 0) { a.state = AsyncBatch::FREE; continue; }
+                if (a.n <= kAsyncHead) { async_submit(e, &a); busy = true; continue; }
+                { const int rc = async_reserve(e, a, a.n); if (rc != FJSP_OK) return rc; }
+                HIP_TRY(hipMemcpyAsync(a.h_ids + 1 + kAsyncHead, a.d_count + 1 + kAsyncHead, (size_t)(a.n - kAsyncHead) * 4, hipMemcpyDeviceToHost, e->copy_stream));
+                HIP_TRY(hipMemcpyAsync(a.h_lp_in + (size_t)kAsyncHead * 2 * KP, a.d_lp_in + (size_t)kAsyncHead * 2 * KP,
+                                       (size_t)(a.n - kAsyncHead) * 2 * KP * 2, hipMemcpyDeviceToHost, e->copy_stream));
+                HIP_TRY(hipEventRecord(a.ev_tail, e->copy_stream));
+                a.state = AsyncBatch::TAIL_COPY;
+                busy = true;
+            } else if (a.state == AsyncBatch::TAIL_COPY) {
+                hipError_t q = block ? hipEventSynchronize(a.ev_tail) : hipEventQuery(a.ev_tail);
+                if (q == hipErrorNotReady) { busy = true; continue; }
+                HIP_TRY(q);
+                async_submit(e, &a);
+                busy = true;
+            } else if (a.state == AsyncBatch::SOLVING || a.state == AsyncBatch::SOLVED) {
+                int sv = a.solved.load();
+                if (sv == 0 && block) {
+                    while ((sv = a.solved.load()) == 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
+                if (sv == 0) { busy = true; continue; }
+                if (sv < 0) { set_error("order-arrival LP failed: " + a.err); return FJSP_E_LP; }
+                HIP_TRY(hipMemcpyAsync(e->d_resume_ids, a.h_ids + 1, (size_t)a.n * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(e->d_resume_x, a.h_x, (size_t)a.n * KP * MP * 8, hipMemcpyHostToDevice, st));
+                if (launch_arrival(b, d_mo, (int)a.n, e->d_resume_ids, e->d_resume_x, d_state, d_reward, d_done, nullptr, st, d_ready,
+                                   mark_resumed) != 0) { set_error("arrival_kernel launch failed"); return FJSP_E_HIP; }
+                HIP_TRY(hipEventRecord(a.ev_up, st));
+                e->lp_solves += a.n;
+                e->async_parked -= a.n;
+                a.state = AsyncBatch::UPLOADING;
+                busy = true;
+            } else if (a.state == AsyncBatch::UPLOADING) {
+                hipError_t q = block ? hipEventSynchronize(a.ev_up) : hipEventQuery(a.ev_up);
+                if (q == hipErrorNotReady) { busy = true; continue; }
+                HIP_TRY(q);
+                a.state = AsyncBatch::FREE;
+            }
+        }
+        if (!block || !busy) return FJSP_OK;
+    }
+}
+}  // namespace
+
+int fjsp_env_step_async(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state, double *d_reward,
+                        uint8_t *d_done, uint8_t *d_ready, void *stream) {
+    if (!e || !d_actions || !d_ready) { set_error("fjsp_env_step_async: null argument"); return FJSP_E_ARG; }
+    if (e->failed) { set_error("fjsp_env_step_async: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
+    DeviceGuard guard(e->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->b.mord) {                               // nothing ever parks: the plain step, every env ready
+        if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, st) != 0) { set_error("step_kernel launch failed"); return FJSP_E_HIP; }
+        HIP_TRY(hipMemsetAsync(d_ready, 1, (size_t)e->b.N, st));
+        return FJSP_OK;
+    }
+    int rc = async_setup(e);
+    if (rc != FJSP_OK) return rc;
+    rc = async_progress(e, d_mo, d_state, d_reward, d_done, d_ready, st, false, true);
+    if (rc != FJSP_OK) { e->failed = true; return rc; }
+    // a free batch for whatever parks in this launch (none free: wait for the oldest ones)
+    AsyncBatch *slot = nullptr;
+    for (int attempt = 0; attempt < 2 && !slot; ++attempt) {
+        for (int off = 0; off < e->ring_n; ++off) {
+            AsyncBatch &a = e->ring[(e->ring_next + off) % e->ring_n];
+            if (a.state == AsyncBatch::FREE) { slot = &a; e->ring_next = (int)((&a - e->ring) + 1) % e->ring_n; break; }
+        }
+        if (!slot) {
+            rc = async_progress(e, d_mo, d_state, d_reward, d_done, d_ready, st, true, true);
+            if (rc != FJSP_OK) { e->failed = true; return rc; }
+        }
+    }
+    if (!slot) { set_error("fjsp_env_step_async: no free batch"); return FJSP_E_STATE; }
+    HIP_TRY(hipMemsetAsync(slot->d_count, 0, 4, st));
+    DevBatch b2 = e->b;
+    b2.pending_count = slot->d_count;
+    b2.lp_in = slot->d_lp_in;
+    if (launch_step(b2, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, st, d_ready) != 0) {
+        set_error("step_kernel launch failed"); return FJSP_E_HIP;
+    }
+    const size_t KP = (size_t)e->b.KP;
+    const uint32_t head = std::min<uint32_t>(kAsyncHead, (uint32_t)e->b.N);
+    HIP_TRY(hipEventRecord(e->ev_step, st));
+    HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_step, 0));
+    HIP_TRY(hipMemcpyAsync(slot->h_ids, slot->d_count, (size_t)(1 + head) * 4, hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(slot->h_lp_in, slot->d_lp_in, (size_t)head * 2 * KP * 2, hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(hipEventRecord(slot->ev_head, e->copy_stream));
+    slot->state = AsyncBatch::HEAD_COPY;
+    return FJSP_OK;
+}
+
+int fjsp_env_arrivals_flush(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, uint8_t *d_ready, void *stream) {
+    if (!e) { set_error("fjsp_env_arrivals_flush: null env"); return FJSP_E_ARG; }
+    if (async_idle(e)) return FJSP_OK;
+    DeviceGuard guard(e->device);
+    const int rc = async_progress(e, d_mo, d_state, d_reward, d_done, d_ready, (hipStream_t)stream, true, false);
+    if (rc != FJSP_OK) e->failed = true;
+    return rc;
+}
+
+int64_t fjsp_env_parked(const fjsp_env *e) { return e ? e->async_parked : 0; }
+int64_t fjsp_env_lp_cache_hits(fjsp_env *e) { if (!e) return 0; std::lock_guard<std::mutex> g(e->lp_cache.mu); return e->lp_cache.hits; }
+
 int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *stream) {
     if (!e) { set_error("fjsp_env_reset: null env"); return FJSP_E_ARG; }
+    if (!async_idle(e)) { set_error("fjsp_env_reset: environments are parked in the asynchronous arrival service; call fjsp_env_arrivals_flush first"); return FJSP_E_STATE; }
     DeviceGuard guard(e->device);
     if (launch_reset(e->b, d_mask, d_state, (hipStream_t)stream) != 0) { set_error("reset_kernel launch failed"); return FJSP_E_HIP; }
     return FJSP_OK;
@@ -580,6 +916,7 @@ int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_
                          double *d_reward, uint8_t *d_done, int16_t *d_trace_km, void *stream) {
     if (!e || !d_actions) { set_error("fjsp_env_step: null argument"); return FJSP_E_ARG; }
     if (e->failed) { set_error("fjsp_env_step: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
+    if (!async_idle(e)) { set_error("fjsp_env_step: environments are parked in the asynchronous arrival service; call fjsp_env_arrivals_flush first"); return FJSP_E_STATE; }
     DeviceGuard guard(e->device);
     if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, d_trace_km, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
@@ -597,6 +934,7 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, 
                      double *d_reward, double *d_state_last, void *stream) {
     if (!e || !d_actions || T <= 0) { set_error("fjsp_env_rollout: bad arguments"); return FJSP_E_ARG; }
     if (e->failed) { set_error("fjsp_env_rollout: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
+    if (!async_idle(e)) { set_error("fjsp_env_rollout: environments are parked in the asynchronous arrival service; call fjsp_env_arrivals_flush first"); return FJSP_E_STATE; }
     DeviceGuard guard(e->device);
     hipStream_t st = (hipStream_t)stream;
     if (!e->b.mord && rollout_lds_bytes(e->b) <= 64 * 1024) {

@@ -1582,7 +1582,7 @@ template <int KC, int V>
 // (four chunks of per-lane operation state do not fit 128 VGPRs: K > 128 runs at half the occupancy instead of spilling)
 __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
                                                       double *state_out, double *reward_out, uint8_t *done_out,
-                                                      int16_t *trace_km) {
+                                                      int16_t *trace_km, uint8_t *ready) {
     constexpr bool SHARED = FJSP_SHARED_TAIL && !is_mord_v<V>;
     const int wave = uni((int)(threadIdx.x >> 6));   // wave-uniform: keeps every record pointer in SGPRs
     const int env_raw = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -1611,6 +1611,12 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
     store_dynamic<KC, V>(w, false);                // diagnostic: state in / state out only
     return;
 #endif
+    if (is_mord_v<V> && ready) {
+        // asynchronous arrival service (fjsp_env_step_async): environments parked at an order arrival sit this launch
+        // out (ready = 0), one that arrival_kernel has just finished in this same call keeps the outputs it was given
+        if (w.pending == 2) { if (w.lane == 0) env_ptr<EnvScalars>(b, env, 0)->pending = 0; return; }
+        if (w.pending == 1) { if (w.lane == 0) ready[env] = 0; return; }
+    }
     const bool need_obs = state_out != nullptr;
     bool go = true;                  // this wave's environment takes a step in this launch
     if (w.done) {
@@ -1649,6 +1655,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
             const uint32_t *src = reinterpret_cast<const uint32_t *>(w.er + b.L.e_lpq);     // u16[2][KP] as KP words
             uint32_t *dst = reinterpret_cast<uint32_t *>(b.lp_in + (size_t)slot * 2 * b.KP);
             for (int i = w.lane; i < b.KP; i += kWave) dst[i] = src[i];
+            if (ready && w.lane == 0) ready[env] = 0;
             store_dynamic<KC, V>(w, false, false);        // (statistics are stale until arrival_kernel finishes the step)
             return;
         }
@@ -1705,6 +1712,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
         if (reward_out) reward_out[env] = reward;
         if (done_out) done_out[env] = (uint8_t)w.done;
         if (trace_km) { trace_km[(size_t)env * 2] = (int16_t)k_sel; trace_km[(size_t)env * 2 + 1] = (int16_t)m_sel; }
+        if (ready) ready[env] = 1;
     }
     store_dynamic<KC, V>(w, false);
     STAMP(w, 12);
@@ -1824,16 +1832,17 @@ __global__ __launch_bounds__(1024) void rollout_policy_kernel(DevBatch b, ActorP
 // fluid LP of the env's live state (class_FJSSP.py:239) and left x in the env record; this kernel runs
 // update_fluid_parameter (:282-306) for that env, then the second half of step().
 template <int KC, int V>
-__global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void arrival_kernel(DevBatch b, const double *mo, int n_pending, double *state_out,
-                                                         double *reward_out, uint8_t *done_out, int16_t *trace_km) {
+__global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void arrival_kernel(DevBatch b, const double *mo, int n_pending, const uint32_t *ids, const double *x_list,
+                                                         double *state_out, double *reward_out, uint8_t *done_out, int16_t *trace_km,
+                                                         uint8_t *ready, int mark_resumed) {
     const int wave = uni((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * (blockDim.x >> 6) + wave;
     if (idx >= n_pending) return;
-    const int env = (int)b.pending_count[1 + idx];
+    const int env = (int)ids[idx];
     W<KC, V> w;
     open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_bytes_per_wave(b.JP, b.MP, b.KP, false), false, true);
     const Layout &L = b.L;
-    const double *xin = b.lp_x + (size_t)idx * b.KP * b.MP;
+    const double *xin = x_list + (size_t)idx * b.KP * b.MP;
     const uint16_t *lpq = reinterpret_cast<const uint16_t *>(w.er + L.e_lpq);
     double *col = reinterpret_cast<double *>(w.er + L.e_col);
 #pragma unroll
@@ -1871,13 +1880,14 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void arrival_kernel(DevBatch 
         reinterpret_cast<uint32_t *>(w.er + L.e_q0)[k] = (uint32_t)w.q0[c];
     }
     wave_sync_global();
-    w.pending = 0;
+    w.pending = mark_resumed ? 2 : 0;       // (asynchronous service: the step launch of this same call must leave this env alone)
     const double reward = env_step_finish<KC, V>(w, mo ? mo + (size_t)env * 4 : nullptr, state_out);
     if (w.lane == 0) {
         const int16_t *stash = reinterpret_cast<const int16_t *>(w.er + L.e_lpq) + 2 * b.KP;
         if (reward_out) reward_out[env] = reward;
         if (done_out) done_out[env] = (uint8_t)w.done;
         if (trace_km) { trace_km[(size_t)env * 2] = stash[0]; trace_km[(size_t)env * 2 + 1] = stash[1]; }
+        if (ready) ready[env] = 1;
     }
     store_dynamic<KC, V>(w, false);
 }
@@ -1951,12 +1961,12 @@ int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStrea
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
-                uint8_t *done, int16_t *trace_km, hipStream_t st) {
+                uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready) {
     const size_t lds = step_lds_bytes(b);
     if (dispatch(b, [&](auto kc, auto v) {
             allow_lds(&step_kernel<decltype(kc)::value, decltype(v)::value>, lds);
             hipLaunchKernelGGL((step_kernel<decltype(kc)::value, decltype(v)::value>), grid_for(b.N), dim3(256), lds, st, b,
-                               actions, mo, autoreset, state, reward, done, trace_km);
+                               actions, mo, autoreset, state, reward, done, trace_km, ready);
         }) != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1996,14 +2006,14 @@ int launch_rollout_policy(const DevBatch &b, const ActorParams &ap, const Policy
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_arrival(const DevBatch &b, const double *mo, int n_pending, double *state, double *reward, uint8_t *done,
-                   int16_t *trace_km, hipStream_t st) {
+int launch_arrival(const DevBatch &b, const double *mo, int n_pending, const uint32_t *ids, const double *x_list, double *state,
+                   double *reward, uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready, bool mark_resumed) {
     const size_t lds = step_lds_bytes(b);
     const dim3 grid((unsigned)((n_pending + 3) / 4));
     auto go = [&](auto kc, auto v) {
         allow_lds(&arrival_kernel<decltype(kc)::value, decltype(v)::value>, lds);
         hipLaunchKernelGGL((arrival_kernel<decltype(kc)::value, decltype(v)::value>), grid, dim3(256), lds, st, b, mo,
-                           n_pending, state, reward, done, trace_km);
+                           n_pending, ids, x_list, state, reward, done, trace_km, ready, mark_resumed ? 1 : 0);
     };
     const int rc = b.variant == FJSP_VARIANT_MO_DFJSP ? dispatch_kc<kDyn>(b.KC, go) : dispatch_kc<kMord>(b.KC, go);
     if (rc != 0) return -1;

@@ -186,6 +186,24 @@ int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int
 int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset,
                          double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace_km, void *stream);
 
+/* Asynchronous form of fjsp_env_step for batches with order arrivals (SO_FJSSP.py:218-231, class_MODFJSP.py:240-276:
+ * an arrival re-solves the fluid LP on the host).  fjsp_env_step waits for those LPs inside every call; here an env
+ * that reaches an arrival PARKS while the rest of the batch keeps stepping: its LP inputs travel to the host, a worker
+ * pool solves them, and a later call uploads the solution and finishes the parked step (arrival_kernel).
+ * d_ready u8[N]: 1 = this call completed a step of env i (d_state / d_reward / d_done row i are that step's), 0 = the
+ * env is parked: its row is untouched, its action was ignored -- present the same action again.  An env's own
+ * trajectory is the one fjsp_env_step produces for the same action sequence (parity is per env); only the interleaving
+ * across envs differs.  fjsp_env_arrivals_flush waits for every parked env and finishes its step (rows + ready = 1);
+ * it must run before fjsp_env_step / _reset / _rollout / destroy are used on the batch again (they return
+ * FJSP_E_STATE while envs are parked).  fjsp_env_parked: parked envs as last seen by the host. */
+int fjsp_env_step_async(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
+                        double *d_reward, uint8_t *d_done, uint8_t *d_ready, void *stream);
+int fjsp_env_arrivals_flush(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done,
+                            uint8_t *d_ready, void *stream);
+int64_t fjsp_env_parked(const fjsp_env *e);
+/* Order-arrival LPs answered from the per-batch memo of (instance, Q, n_now) -> x (a pure function: same bits as a solve). */
+int64_t fjsp_env_lp_cache_hits(fjsp_env *e);
+
 /* T fused steps in ONE launch (rule-sweep harnesses, MO_DFJSP.py:481-518 style):
  * d_actions u8[T][N][2]; d_mo as in fjsp_env_step (constant over the T steps);
  * envs that finish early idle (no autoreset).

@@ -767,3 +767,76 @@ def test_wrong_tensor_arguments_are_rejected_before_any_launch(torch_gpu):
     # inputs of another dtype / on the host are converted, as before
     b.step(torch.zeros(N, 2, dtype=torch.int64), mo=torch.tensor([[0.0, 1.0, 0.0, 0.0]] * N, dtype=torch.float32))
     assert int((b.read()["status"] != 0).sum()) == 0
+
+
+def test_async_arrival_service_keeps_every_env_on_its_own_trajectory(torch_gpu):
+    """fjsp_env_step_async: envs that reach an order arrival park while the LP is solved in the background and the
+    rest of the batch keeps stepping.  Every env must still walk exactly the trajectory the blocking fjsp_env_step
+    gives it for the same action sequence: same rewards step by step, same final makespan / tardiness / energy."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, VARIANT_MO_DFJSP, global_actions
+    insts, _, _ = H.load_suite("mo_dfjsp")
+    s = H.instance_set_from(insts)
+    N = 96
+    acts = torch.from_numpy(global_actions(21, 0, N, 1400, 12, 10)).cuda()      # [T, N, 2]
+    mo = torch.zeros(N, 4, dtype=torch.float64, device="cuda"); mo[:, 0] = 1.0
+    idx = torch.arange(N, device="cuda")
+    # ---- blocking service
+    a = EnvBatch(s, N, variant=VARIANT_MO_DFJSP, rng_seed=5)
+    a.reset()
+    rew_a = torch.zeros(1400, N, dtype=torch.float64, device="cuda")
+    steps_a = torch.zeros(N, dtype=torch.int64, device="cuda")
+    t = 0
+    while True:
+        live = a.done == 0
+        _, r, d = a.step(acts[t], mo=mo)
+        rew_a[t] = torch.where(live, r, torch.zeros_like(r))
+        steps_a += live.long()
+        t += 1
+        if t % 50 == 0 and bool((a.done != 0).all()):
+            break
+        assert t < 1400
+    fa = a.read()
+    # ---- asynchronous service: per-env cursor into the same action sequences
+    b = EnvBatch(s, N, variant=VARIANT_MO_DFJSP, rng_seed=5)
+    b.reset()
+    cursor = torch.zeros(N, dtype=torch.int64, device="cuda")
+    rew_b = torch.zeros(1400, N, dtype=torch.float64, device="cuda")
+    done_prev = torch.zeros(N, dtype=torch.bool, device="cuda")
+    calls, parked_seen = 0, 0
+    while True:
+        cur = acts[cursor.clamp(max=1399), idx]
+        _, r, d, ready = b.step_async(cur, mo=mo)
+        took = (ready != 0) & ~done_prev
+        rew_b[cursor.clamp(max=1399), idx] = torch.where(took, r, rew_b[cursor.clamp(max=1399), idx])
+        cursor += took.long()
+        done_prev = done_prev | ((ready != 0) & (d != 0))
+        calls += 1
+        if calls % 25 == 0:
+            parked_seen = max(parked_seen, b.parked)
+            if bool(done_prev.all()):
+                break
+        assert calls < 6000
+    b.flush_arrivals(mo)
+    assert b.parked == 0 and parked_seen > 0
+    fb = b.read()
+    assert torch.equal(cursor, steps_a), "steps per env"
+    assert torch.equal(rew_a, rew_b), "per-step rewards"
+    for k in ("delay_time_sum", "makespan", "completion_time", "step_count", "energy_consumption", "done"):
+        assert torch.equal(fa[k], fb[k]), k
+    assert int(((fb["status"] & ~4) != 0).sum()) == 0
+    assert b.lp_solves == a.lp_solves
+    # the blocking entry points refuse to run while envs are parked
+    c = EnvBatch(s, N, variant=VARIANT_MO_DFJSP, rng_seed=5); c.reset()
+    from deep_reinforcement_learning_for_fjsp_amd._capi import FjspError
+    refused = False
+    for t in range(400):
+        c.step_async(acts[t], mo=mo)
+        try:
+            c.step(acts[t], mo=mo)
+        except FjspError as err:
+            refused = err.code == -7          # FJSP_E_STATE
+            break
+    assert refused
+    c.flush_arrivals(mo)
+    c.step(acts[0], mo=mo)
