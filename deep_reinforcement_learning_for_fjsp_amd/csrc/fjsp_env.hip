@@ -500,13 +500,16 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             reinterpret_cast<double *>(ip(i, L.i_ss))[7] = best;
         }
         // algorithmic HBM bytes of one env-step (DESIGN.md "bytes per env-step"):
-        //   static per-k rows (kinfoA/B, elig, fmask, first4 u32; rate_sum, time_sum f64)  K * 36
+        //   static per-k rows (kinfoB, elig, fmask u32; rate_sum, time_sum f64; see per_k below)    K * 28 ..
         //   job table read (due, jinfo, jst) + jst write-back                               njobs * 16
         //   machine lanes tend/mjob read + write                                            M * 16
         //   instance header + EnvScalars read + write                                       16 + 2 * 144
         //   column gather at k_sel (p u16, un/arr/rate f64) + un write                      M * 26 + 8
         //   actions in, state/reward/done out                                               2 + S*8 + 8 + 1
-        bytes_acc += in.K * 36.0 + nj * 16.0 + in.M * 16.0 + 304.0 + in.M * 26.0 + 8.0 + 2.0 + b.state_size * 8.0 + 9.0;
+        // (per-k rows: kB, elig, fmask u32 + rate_sum, time_sum f64 = 28 B; + kA when a kind can have several jobs, + first4
+        //  beyond 8 machines (CPython set order); + the 64-byte statistics row, read and written, in multi-job batches)
+        const double per_k = 28.0 + (b.single_job ? 0.0 : 4.0) + (b.MP > 8 ? 4.0 : 0.0) + (b.single_job ? 0.0 : 128.0);
+        bytes_acc += in.K * per_k + nj * 16.0 + in.M * 16.0 + 304.0 + in.M * 26.0 + 8.0 + 2.0 + b.state_size * 8.0 + 9.0;
         if (dyn) bytes_acc += in.M * 14.0 + 2.0 * sizeof(DynScalars);    // power column, idle power, last-task ends r/w, DynScalars r/w
     }
     e->step_bytes = (int64_t)(bytes_acc / (double)NI + 0.5);

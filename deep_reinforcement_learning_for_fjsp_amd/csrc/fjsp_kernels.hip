@@ -298,12 +298,13 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, boo
 // Bind the wave to its records and bring the environment in.  All loads below are
 // independent of each other (bounds come from the kernel arguments, not from the
 // instance header), so they are in flight together: one memory round trip.
-template <int KC, int V>
+// SJ: 1 = the batch is known (at compile time) to have one job per kind, 0 = known not to, -1 = look at the batch
+template <int KC, int V, int SJ = -1>
 __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
                                          bool load_state, bool want_stats = false) {
     w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
-    w.single_job = !is_mord_v<V> && b->single_job != 0;
+    w.single_job = SJ < 0 ? (!is_mord_v<V> && b->single_job != 0) : (SJ != 0);
     w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats;
     w.env = env;
     w.lane = (int)__lane_id();
@@ -1578,7 +1579,9 @@ __global__ __launch_bounds__(256) void reset_kernel(DevBatch b, const uint8_t *m
 // One step of every environment.  Single-order variants share the observation tail inside the workgroup
 // (observe_tail above): every live wave of a workgroup passes the same four barriers, whatever happened to its
 // environment (finished episode, invalid rule), so nothing below returns between the first barrier and the last.
-template <int KC, int V>
+// SJ: one job per kind in every instance of the batch (compile-time: the single-job kernel carries none of the list walks,
+// statistics rows or their registers)
+template <int KC, int V, bool SJ>
 // (four chunks of per-lane operation state do not fit 128 VGPRs: K > 128 runs at half the occupancy instead of spilling)
 __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset,
                                                       double *state_out, double *reward_out, uint8_t *done_out,
@@ -1604,7 +1607,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
         a0 = uni((int)actions[(size_t)env * 2]); a1 = uni((int)actions[(size_t)env * 2 + 1]);
     }
     const uint32_t lds_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
-    open_env<KC, V>(w, &b, env, fjsp_lds + wave * lds_stride, false, true, true);
+    open_env<KC, V, SJ ? 1 : 0>(w, &b, env, fjsp_lds + wave * lds_stride, false, true, true);
     if (env_raw >= b.N) return;                       // (a finished wave no longer counts at the workgroup's barriers)
     STAMP(w, 0);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 4
@@ -1964,9 +1967,18 @@ int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int
                 uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready) {
     const size_t lds = step_lds_bytes(b);
     if (dispatch(b, [&](auto kc, auto v) {
-            allow_lds(&step_kernel<decltype(kc)::value, decltype(v)::value>, lds);
-            hipLaunchKernelGGL((step_kernel<decltype(kc)::value, decltype(v)::value>), grid_for(b.N), dim3(256), lds, st, b,
-                               actions, mo, autoreset, state, reward, done, trace_km, ready);
+            constexpr int KC = decltype(kc)::value, V = decltype(v)::value;
+            if constexpr (!is_mord_v<V>) {
+                if (b.single_job) {
+                    allow_lds(&step_kernel<KC, V, true>, lds);
+                    hipLaunchKernelGGL((step_kernel<KC, V, true>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, autoreset, state, reward,
+                                       done, trace_km, ready);
+                    return;
+                }
+            }
+            allow_lds(&step_kernel<KC, V, false>, lds);
+            hipLaunchKernelGGL((step_kernel<KC, V, false>), grid_for(b.N), dim3(256), lds, st, b, actions, mo, autoreset, state, reward, done,
+                               trace_km, ready);
         }) != 0) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
