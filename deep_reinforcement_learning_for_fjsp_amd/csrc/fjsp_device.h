@@ -92,7 +92,9 @@ struct Layout {
     uint32_t e_tend;    // i32[MP]  machine.time_end
     uint32_t e_mjob;    // i32[MP]  machine.job_object (job index)
     uint32_t e_jst;     // u32[JP]  job state words
-    uint32_t e_un;      // f64[KP][MP] machine.unprocessed_rj_dict (op-major)
+    uint32_t e_un;      // f64[KP][MP] machine.unprocessed_rj_dict (op-major); batches with several jobs per kind
+    uint32_t e_asg;     // u8[KP]   single-job batches: the machine operation type k was assigned to (0xFF: not yet).  There every
+                        //          type is dispatched once, so unprocessed[k][m] = arrival[k][m] - (assigned[k] == m): no matrix
     // multi-order batches only: the fluid tables change at every order arrival, so they live per environment
     uint32_t e_q0;      // u32[KP]  fluid_unprocessed_number_start
     uint32_t e_fmask;   // u32[KP]

@@ -388,7 +388,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         }
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
-        L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(MP * KP * 8, 8);
+        L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(b.single_job ? 8 : MP * KP * 8, 8); L.e_asg = take(KP, 4);
         if (b.mord) {
             L.e_q0 = take(KP * 4, 4); L.e_fmask = take(KP * 4, 4); L.e_rsum = take(KP * 8, 8); L.e_tsum = take(KP * 8, 8);
             L.e_col = take(MP * KP * 16, 16); L.e_lpq = take(KP * 4 + 8, 4);
@@ -508,8 +508,11 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         //   actions in, state/reward/done out                                               2 + S*8 + 8 + 1
         // (per-k rows: kB, elig, fmask u32 + rate_sum, time_sum f64 = 28 B; + kA when a kind can have several jobs, + first4
         //  beyond 8 machines (CPython set order); + the 64-byte statistics row, read and written, in multi-job batches)
-        const double per_k = 28.0 + (b.single_job ? 0.0 : 4.0) + (b.MP > 8 ? 4.0 : 0.0) + (b.single_job ? 0.0 : 128.0);
-        bytes_acc += in.K * per_k + nj * 16.0 + in.M * 16.0 + 304.0 + in.M * 26.0 + 8.0 + 2.0 + b.state_size * 8.0 + 9.0;
+        //  single-job batches: + the assigned-machine byte; the column gather has no unprocessed entries there (p u16 + {arrival,
+        //  rate} f64 = 18 B per machine, one byte written) against p + unprocessed + {arrival, rate} = 26 B and 8 B written)
+        const double per_k = 28.0 + (b.single_job ? 1.0 : 4.0) + (b.MP > 8 ? 4.0 : 0.0) + (b.single_job ? 0.0 : 128.0);
+        const double gather = b.single_job ? in.M * 18.0 + 1.0 : in.M * 26.0 + 8.0;
+        bytes_acc += in.K * per_k + nj * 16.0 + in.M * 16.0 + 304.0 + gather + 2.0 + b.state_size * 8.0 + 9.0;
         if (dyn) bytes_acc += in.M * 14.0 + 2.0 * sizeof(DynScalars);    // power column, idle power, last-task ends r/w, DynScalars r/w
     }
     e->step_bytes = (int64_t)(bytes_acc / (double)NI + 0.5);

@@ -243,7 +243,8 @@ struct W {
     // makes the compiler spill it to scratch and re-load fields through memory)
     int KP, MP, JP, n_obs, n_static, state_size;
     bool single_job;         // DevBatch::single_job
-    uint32_t e_jst, e_tend, e_mjob, e_un, e_dyn, e_stats;
+    bool jreg;               // (compile-time single-job kernels of <= 64 operation types) the job words live in registers, see jsk
+    uint32_t e_jst, e_tend, e_mjob, e_un, e_dyn, e_stats, e_asg;
     const double *sstate;
     double fluid_completed_time;
     int env, inst, lane;
@@ -262,6 +263,12 @@ struct W {
     const unsigned char *ir;
     // lane = operation type
     uint32_t kA[KC], kB[KC], elig[KC], fmask[KC], first4[KC];
+    // jreg: state word and due date of THE job of this lane's kind (one job per kind: job index == kind index), kept per
+    // lane instead of per job in LDS: every list walk, dispatch and release then stays inside the lane's registers
+    uint32_t jsk[KC];
+    int duek[KC];
+    // single-job batches: the machine this lane's operation type was assigned to (0xFF: not yet) -- Layout::e_asg
+    uint32_t asg[KC];
     int q0[KC], tot[KC];     // fluid_unprocessed_number_start; jobs of the kind that have arrived
     double rate_sum[KC], time_sum[KC];
     int nun[KC], cnt_a[KC], cnt_e[KC], max_a[KC], fifo_cnt[KC], head_job[KC], due_min[KC], tard[KC];
@@ -305,7 +312,8 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
     w.state_size = b->state_size;
     w.single_job = SJ < 0 ? (!is_mord_v<V> && b->single_job != 0) : (SJ != 0);
-    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats;
+    w.jreg = SJ == 1 && KC == 1;
+    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats; w.e_asg = b->L.e_asg;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = b->n_inst == b->N ? env : env % b->n_inst;     // (one instance per environment: no division)
@@ -336,6 +344,8 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         // the file order of the first four machines only matters to CPython's set order beyond 8 machines (fjsp_pyset.h)
         w.first4[c] = 0;
         if (MP > 8) w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
+        w.asg[c] = 0xFFu;
+        if (w.single_job && load_state) w.asg[c] = reinterpret_cast<const uint8_t *>(er + L.e_asg)[k];
         if (is_mord_v<V> && load_state) {      // tables of the last LP of THIS environment
             w.fmask[c] = reinterpret_cast<const uint32_t *>(er + L.e_fmask)[k];
             w.rate_sum[c] = reinterpret_cast<const double *>(er + L.e_rsum)[k];
@@ -407,11 +417,23 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     }
     w.mmask = w.M >= 32 ? 0xFFFFFFFFu : ((1u << w.M) - 1u);
     w.ipw_m = ipw0; w.tlast_m = -1; w.energy = 0; w.energy_last = 0;
-    w.dueL[w.lane] = due0;
-    for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
+    if (w.jreg) {
+        // lane k takes the words of job r(k) from lane r(k) (which fetched job r's words): one cross-lane move each
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int r = (int)((w.kB[c] >> 16) & 0xFFu) & 63;
+            w.duek[c] = __shfl(due0, r, 64);
+            w.jsk[c] = (uint32_t)__shfl((int)jst0, r, 64);
+        }
+    } else {
+        w.dueL[w.lane] = due0;
+        for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
+    }
     if (!load_state) return;
-    w.jstL[w.lane] = jst0;
-    for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + L.e_jst)[n];
+    if (!w.jreg) {
+        w.jstL[w.lane] = jst0;
+        for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + L.e_jst)[n];
+    }
     w.t = uni(sc.t); w.step_count = uni(sc.step_count); w.done = uni(sc.done); w.n_unassigned = uni(sc.n_unassigned);
     w.status = uniu(sc.status); w.seq_ctr = uniu(sc.seq_ctr); w.rng_calls = uniu(sc.rng_calls); w.busy = uniu(sc.busy);
     w.completion = uni(sc.completion); w.completion_last = uni(sc.completion_last);
@@ -423,7 +445,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.tend_m = w.lane < w.M ? tend0 : 0;
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
     if (V == kDyn) { w.tlast_m = w.lane < w.M ? tlast0 : -1; w.energy = en0; w.energy_last = enl0; }
-    if (un_lds) {
+    if (un_lds && !w.single_job) {
         const double *src = reinterpret_cast<const double *>(er + L.e_un);
         for (int i = w.lane; i < w.K * MP; i += kWave) w.unp[i] = src[i];
     }
@@ -465,7 +487,13 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds, bool sto
         if (w.lane >= 10 && w.lane < 15) ds->obs_hi[w.lane - 10] = w.obs_prev_l;
         if (w.lane < w.M) reinterpret_cast<int32_t *>(er + w.e_dyn + sizeof(DynScalars))[w.lane] = w.tlast_m;
     }
-    for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + w.e_jst)[n] = w.jstL[n];
+    if (w.jreg) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)       // the lane of a kind's first operation writes the kind's job word back
+            if (((w.kB[c] >> 24) & 2u) && (w.kB[c] & 0xFFu) == 0) reinterpret_cast<uint32_t *>(er + w.e_jst)[(w.kB[c] >> 16) & 0xFFu] = w.jsk[c];
+    } else {
+        for (int n = w.lane; n < w.njobs; n += kWave) reinterpret_cast<uint32_t *>(er + w.e_jst)[n] = w.jstL[n];
+    }
     if (!w.single_job && store_stats) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
@@ -477,7 +505,7 @@ __device__ __forceinline__ void store_dynamic(W<KC, V> &w, bool un_lds, bool sto
             sp[3] = make_uint4((uint32_t)w.tot[c], 0u, 0u, 0u);
         }
     }
-    if (un_lds) {
+    if (un_lds && !w.single_job) {
         double *dst = reinterpret_cast<double *>(er + w.e_un);
         for (int i = w.lane; i < w.K * w.MP; i += kWave) dst[i] = w.unp[i];
     }
@@ -502,8 +530,8 @@ __device__ __forceinline__ void compute_params(W<KC, V> &w) {
             const uint32_t a = w.kA[c];
             const int jbeg = (int)(a & 0xFFFFu), j = (int)(w.kB[c] & 0xFFu);
             const bool has = (a >> 16) != 0;
-            const uint32_t js = w.jstL[jbeg];
-            const int d = w.dueL[jbeg];
+            const uint32_t js = w.jreg ? w.jsk[c] : w.jstL[jbeg];
+            const int d = w.jreg ? w.duek[c] : w.dueL[jbeg];
             const int nj = (int)(js & 0xFFu);
             const bool in = has && nj <= j;                             // the job's stage-j task is still unassigned
             const int da = t - d;                                       // :138
@@ -810,7 +838,9 @@ __device__ __forceinline__ double gap_ave3(const W<KC, V> &w, int m0, int m1, in
             if (on_m) {
                 const int o = k * w.MP + m;
                 const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
-                g = w.unp[o] - (ar.x - dt * ar.y);
+                // (single-job batches: unprocessed = arrival, less one where this type was assigned to m)
+                const double un_km = w.single_job ? (w.asg[c] == (uint32_t)m ? ar.x - 1.0 : ar.x) : w.unp[o];
+                g = un_km - (ar.x - dt * ar.y);
             }
             row[k] = g;
             cnt_q[q] += __builtin_popcountll(__ballot(on_m));
@@ -849,8 +879,9 @@ __device__ __forceinline__ int machine_select(W<KC, V> &w, int a1, int k_sel, ui
         // op-major layout: the column of k_sel is MP contiguous entries per array (a handful of cache lines)
         const int o = k_sel * w.MP + w.lane;
         pm = w.p_i[o];
-        un = w.unp[o];
         const double2 ar = *reinterpret_cast<const double2 *>(w.col_i + 2 * o);
+        // (single-job batches: k_sel has not been dispatched yet -- it is available -- so its unprocessed is its arrival)
+        un = w.single_job ? ar.x : w.unp[o];
         g = un - (ar.x - fluid_dt(w) * ar.y);
         if (V == kDyn) en = pm * (int)w.pw_i[o];                 // energy_mrj_dict class_MODFJSP.py:178
     }
@@ -1037,9 +1068,21 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
         if (w.lane == m_sel) w.tlast_m = time_end;
     }
     const int nj = (int)(kb & 0xFFu) + 1;       // the FIFO head of (r, j) is at stage j; it moves to j + 1
+    if (w.jreg) {
+        const uint32_t r_sel = (kb >> 16) & 0xFFu;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            if (((w.kB[c] >> 16) & 0xFFu) == r_sel) w.jsk[c] = jst_pack(kNoSeq, (uint32_t)nj);      // :186-191
+    }
+    if (w.single_job) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            if (c == cs && w.lane == ls) w.asg[c] = (uint32_t)m_sel;         // :198 unprocessed_rj_dict[m][(r, j)] -= 1
+    }
     if (w.lane == 0) {
-        w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);                        // :186-191
-        w.unp[k_sel * w.MP + m_sel] = un_sel - 1.0;                          // :198
+        if (!w.jreg) w.jstL[job] = jst_pack(kNoSeq, (uint32_t)nj);           // :186-191
+        if (w.single_job) reinterpret_cast<uint8_t *>(w.er + w.e_asg)[k_sel] = (uint8_t)m_sel;
+        else w.unp[k_sel * w.MP + m_sel] = un_sel - 1.0;                     // :198
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
@@ -1051,7 +1094,7 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
     if (time_end > w.completion) w.completion = time_end;
     if (nj == Jr) {                                                          // :200-202
         w.n_unassigned--;
-        const int late = time_end - w.dueL[job];
+        const int late = time_end - (w.jreg ? rl(pick<KC>(w.duek, cs), ls) : w.dueL[job]);
         w.tard_done += late > 0 ? late : 0;
     }
     uint32_t idle = ~w.busy & w.mmask;
@@ -1068,7 +1111,13 @@ __device__ __forceinline__ void dispatch_and_advance(W<KC, V> &w, const DevBatch
             const int jb = mj & 0xFFFF, kk = (mj >> 16) - 1;
             if (kk >= 0) {
                 const int n2 = (int)(rlu(pick<KC>(w.kB, kk >> 6), kk & 63) & 0xFFu);   // stage index of kk
-                if (w.lane == 0) w.jstL[jb] = jst_pack(w.seq_ctr, (uint32_t)n2);
+                if (w.jreg) {
+#pragma unroll
+                    for (int c = 0; c < KC; ++c)
+                        if ((int)((w.kB[c] >> 16) & 0xFFu) == jb) w.jsk[c] = jst_pack(w.seq_ctr, (uint32_t)n2);
+                } else if (w.lane == 0) {
+                    w.jstL[jb] = jst_pack(w.seq_ctr, (uint32_t)n2);
+                }
                 w.seq_ctr++;
 #pragma unroll
                 for (int c = 0; c < KC; ++c)
@@ -1287,7 +1336,7 @@ __device__ __forceinline__ void observe_finish(W<KC, V> &w) {
         // (ineligible entries +0.0, an exact identity of the running sum) go to the three LDS rows and lanes
         // 0..2 walk one row each.  In the step kernel the unprocessed matrix lives in HBM and lane 0 has just
         // updated one element of it, so that store is drained first.
-        wave_sync_global();
+        if (!w.single_job) wave_sync_global();
         double gave_m = 0.0;                       // lane m (< M): gap_ave of machine m
         for (int m0 = 0; m0 < M; m0 += 3) {
             const double v = gap_ave3<KC, V, RING>(w, m0, m0 + 1 < M ? m0 + 1 : -1, m0 + 2 < M ? m0 + 2 : -1);
@@ -1397,11 +1446,23 @@ __device__ __forceinline__ void init_episode(W<KC, V> &w, const DevBatch *b, dou
     } else {
         w.n_unassigned = w.njobs;
         w.seq_ctr = (uint32_t)w.njobs;
-        for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack((uint32_t)n, 0u);  // class_FJSSP.py:225
+        if (w.jreg) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) w.jsk[c] = jst_pack((w.kB[c] >> 16) & 0xFFu, 0u);                 // (job n = kind n)
+        } else {
+            for (int n = w.lane; n < w.njobs; n += kWave) w.jstL[n] = jst_pack((uint32_t)n, 0u);  // class_FJSSP.py:225
+        }
     }
-    for (int i = w.lane; i < w.K * w.MP; i += kWave) w.unp[i] = w.col_i[2 * i];              // :304
-    wave_sync();
-    wave_sync_global();       // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
+    if (w.single_job) {
+        // :304 unprocessed = arrival: nothing assigned yet
+#pragma unroll
+        for (int c = 0; c < KC; ++c) { w.asg[c] = 0xFFu; reinterpret_cast<uint8_t *>(w.er + w.e_asg)[c * kWave + w.lane] = 0xFFu; }
+        wave_sync();
+    } else {
+        for (int i = w.lane; i < w.K * w.MP; i += kWave) w.unp[i] = w.col_i[2 * i];          // :304
+        wave_sync();
+        wave_sync_global();   // the step kernel keeps the unprocessed matrix in HBM; later lanes gather from it
+    }
     compute_params<KC, V>(w);
     if (cached_obs) {
         w.obs_prev_l = w.lane < w.n_obs ? reinterpret_cast<const double *>(w.ir + b->L.i_obs0)[w.lane] : 0.0;
