@@ -279,7 +279,7 @@ def main():
                        "host_prep_s": round(t_prep, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "step_kernel<1, 0>", "bytes_per_env_step": env.step_bytes,
+                         "kernel": "step_kernel<1, 0, true>", "bytes_per_env_step": env.step_bytes,
                          "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": region_us,
                          "launch_us_per_launch_events": kern_us},
             "cpu_baseline": cpu,

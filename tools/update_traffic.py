@@ -19,12 +19,12 @@ from bench import csrc_hash  # noqa: E402
 src = sys.argv[1]
 tag = os.path.basename(src.rstrip("/")).replace("prof_", "")
 pm = json.load(open(os.path.join(src, "pmc_means.json")))
-sk = pm["fjsp::step_kernel<1, 0>"]
+sk = pm["fjsp::step_kernel<1, 0, true>"]
 fetch = sk["FETCH_SIZE"] * 1024 * 2.0
 write = sk["WRITE_SIZE"] * 1024
 bench = json.load(open(os.path.join(src, "bench.json")))
 out = {
-    "kernel": "fjsp::step_kernel<1, 0>",
+    "kernel": "fjsp::step_kernel<1, 0, true>",
     "envs": 4096,
     "fetch_size_kib_per_launch_reported": sk["FETCH_SIZE"],
     "write_size_kib_per_launch_reported": sk["WRITE_SIZE"],
