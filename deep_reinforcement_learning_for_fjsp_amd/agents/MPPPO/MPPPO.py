@@ -129,6 +129,7 @@ class PPOLearner(object):
         self.hp.update(hyper or {})
         self.device = torch.device(device)
         self.fused_learn = True            # GPU batches of >= 32 k samples train through agents/fused_mlp.py
+        self.mfma_learn = True             # ... with forward + loss + backward of a network in ONE launch (csrc/fjsp_mlp_train.hip)
         self._fused = None
         gen_state = torch.random.get_rng_state()
         torch.manual_seed(seed)            # identical initial parameters on every rank
@@ -264,18 +265,26 @@ class PPOLearner(object):
         else:
             reduce = None
         actions_f = actions.to(torch.float32).contiguous()
-        states = states.contiguous()
+        states, returns, old_log_prob = states.contiguous(), returns.contiguous(), old_log_prob.contiguous()
         advantages = (returns - critic.forward(states).squeeze(1)).contiguous()                    # :263
         c_loss = a_loss = None
+        one_launch = self.mfma_learn and actor.mfma_pass_supported() and critic.mfma_pass_supported()
         for _ in range(hp["learning_iterations_per_round_critic"]):
-            critic.forward(states)
-            c_loss = critic.critic_loss(returns, count)                                           # F.mse_loss, :318
+            if one_launch:
+                c_loss = critic.train_pass(1, states, returns, None, None, count)                 # forward, F.mse_loss (:318), backward
+            else:
+                critic.forward(states)
+                c_loss = critic.critic_loss(returns, count)
+                if self.train_critic:
+                    critic.backward()
             if self.train_critic:
-                critic.backward()
                 critic.step(reduce)
-            actor.forward(states)
-            a_loss = actor.actor_loss(actions_f, old_log_prob, advantages, hp["clip_epsilon"], count)   # :325-352
-            actor.backward()
+            if one_launch:
+                a_loss = actor.train_pass(0, states, actions_f, old_log_prob, advantages, count, hp["clip_epsilon"])   # :325-352
+            else:
+                actor.forward(states)
+                a_loss = actor.actor_loss(actions_f, old_log_prob, advantages, hp["clip_epsilon"], count)
+                actor.backward()
             actor.step(reduce)
         self.equalise_policies()
         return c_loss[0].clone(), a_loss[0].clone()

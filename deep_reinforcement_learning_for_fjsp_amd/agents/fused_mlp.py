@@ -71,7 +71,8 @@ class FusedMLP(object):
                      dout=torch.empty(n, self.out, **f), da=torch.empty(n, self.H, **f), db=torch.empty(n, self.H, **f),
                      partial=torch.empty(nparts, max(self.H, self.out), **f), nparts=nparts,
                      loss_partial=torch.empty(self._lib.fjsp_ppo_partials(n), **f), loss=torch.zeros(1, **f))
-            self._buf = {n: b}
+            self._buf = {k: v for k, v in self._buf.items() if isinstance(k, tuple)}
+            self._buf[n] = b
         return b
 
     def _stream(self):
@@ -125,7 +126,7 @@ class FusedMLP(object):
 
     @torch.no_grad()
     def backward(self):
-        b = self._buf[next(iter(self._buf))]
+        b = self._buf[next(k for k in self._buf if not isinstance(k, tuple))]
         l1, l2, l3 = self.lin
         gw1, gb1, gw2, gb2, gw3, gb3 = self.views
         dout, x, h1, h2 = b["dout"], b["x"], b["h1"], b["h2"]
@@ -137,6 +138,28 @@ class FusedMLP(object):
         torch.mm(b["da"], l2.weight, out=b["db"])                                  # d h1
         self._bias_grad(b["db"], h1, gb1, b)
         self._weight_grad(b["db"], x, gw1)
+
+    # -- forward + loss + backward in ONE launch (csrc/fjsp_mlp_train.hip) --------------------------------------------
+    def mfma_pass_supported(self):
+        """The one-launch training pass covers the reference's shapes: 128 hidden units, <= 31 state features, <= 32 outputs."""
+        return self.H == 128 and self.lin[0].in_features <= 31 and self.out <= 32
+
+    @torch.no_grad()
+    def train_pass(self, mode, x, aux0, aux1, aux2, count, clip_epsilon=0.0):
+        """mode 0: actor (aux = actions f32, old log-probabilities, advantages); mode 1: critic (aux0 = returns).
+        Fills the flat gradient buffer and returns the loss (f32[1])."""
+        n = x.shape[0]
+        key = ("pass", n)
+        b = self._buf.get(key)
+        if b is None:
+            groups = self._lib.fjsp_mlp_train_groups(n)
+            f = dict(dtype=torch.float32, device=self.device)
+            b = dict(groups=groups, partial=torch.empty(groups, self.numel, **f), loss_partial=torch.empty(groups, **f), loss=torch.zeros(1, **f))
+            self._buf[key] = b
+        _capi.check(self._lib.fjsp_mlp_train_pass(int(mode), _p(self.flat), _p(x), n, self.lin[0].in_features, self.H, self.out, _p(aux0), _p(aux1),
+                                                  _p(aux2), _p(count), float(clip_epsilon), _p(b["partial"]), b["groups"], _p(b["loss_partial"]),
+                                                  _p(self.grad), _p(b["loss"]), self._stream()))
+        return b["loss"]
 
     # -- optimiser step --------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -327,6 +327,21 @@ int fjsp_relu_bwd_bias(float *d_dh, const float *d_h, int32_t n, int32_t width, 
 int fjsp_adam_clip_step(float *d_params, const float *d_grads, float *d_exp_avg, float *d_exp_avg_sq, int32_t n, float max_norm, float lr,
                         float beta1, float beta2, float eps, float *d_step, float *d_scratch64, void *stream);
 
+/* ---- one launch per network and learning iteration: forward + loss + backward on the f32 matrix cores
+ * (csrc/fjsp_mlp_train.hip), for the reference's Linear-ReLU-Linear-ReLU-Linear networks with 128 hidden units
+ * (agents/MPPPO/MPPPO.py:27-70 actor / critic; the iteration is :314-370).  d_params: the network's parameters in ONE
+ * flat f32 buffer, order W1[128][S] b1[128] W2[128][128] b2[128] W3[n_out][128] b3[n_out] (16-byte aligned);
+ * d_x f32[n][S].  mode 0 (actor): d_aux0 = actions (flat index as f32), d_aux1 = old log-probabilities, d_aux2 =
+ * advantages; loss and gradient as fjsp_ppo_actor_loss.  mode 1 (critic, n_out == 1): d_aux0 = returns; loss as
+ * fjsp_ppo_critic_loss.  Outputs: d_grad f32[numel] = d loss / d params (same order as d_params), *d_loss.
+ * Scratch: d_partial f32[n_groups][numel], d_loss_partial f32[n_groups], n_groups = fjsp_mlp_train_groups(n).
+ * FJSP_E_UNSUPPORTED unless state_size <= 31, hidden == 128, n_out <= 32. */
+int fjsp_mlp_train_groups(int32_t n);
+int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden,
+                        int32_t n_out, const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count,
+                        float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

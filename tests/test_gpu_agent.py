@@ -483,3 +483,49 @@ def test_fused_ppo_learning_matches_autograd(torch_gpu):
     actor_tr, _ = fus._fused_nets()
     assert actor_tr.flat.numel() == sum(p.numel() for p in fus.actor_new.parameters())
     assert fus.actor_new.layers[0].weight.data_ptr() == actor_tr.flat.data_ptr()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,S,A", [(1000, 20, 24), (32 * 300 + 7, 18, 30), (5, 30, 32), (70000, 25, 6)])
+def test_one_launch_training_pass_matches_autograd(torch_gpu, n, S, A):
+    """fjsp_mlp_train_pass (csrc/fjsp_mlp_train.hip: forward + loss + backward of a 2 x 128 network in one launch on the f32
+    matrix cores) against autograd on the same weights and samples: loss and every parameter gradient, actor and critic,
+    sample counts that are not a multiple of the 32-sample tile.  Tolerance: f32 reassociation of sums over n samples."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO import MPPPO as M
+    from deep_reinforcement_learning_for_fjsp_amd.agents import fused_mlp
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cuda").manual_seed(n + S)
+    torch.manual_seed(3)
+    actor, critic = M.ActorNet(S, 128, 2, A).to(dev), M.CriticNet(S, 128, 2, 1).to(dev)
+    with torch.no_grad():
+        for net in (actor, critic):
+            for prm in net.parameters():
+                if prm.dim() == 1:
+                    prm.copy_(torch.randn(prm.shape, device=dev, generator=g) * 0.1)       # biases away from 0: the bias path is exercised
+    x = torch.randn(n, S, device=dev, generator=g)
+    actions = torch.randint(0, A, (n,), device=dev, generator=g)
+    old_lp = -torch.rand(n, device=dev, generator=g) * 3 - 0.2
+    adv = torch.randn(n, device=dev, generator=g)
+    ret = torch.randn(n, device=dev, generator=g)
+    count = torch.full((1,), float(n), device=dev)
+    # autograd
+    new_lp = actor.log_prob(x, actions)
+    a_loss = -(M.actor_loss_terms(new_lp, old_lp, adv, 0.2)).sum() / n
+    a_grads = torch.autograd.grad(a_loss, list(actor.parameters()))
+    c_loss = ((critic(x).squeeze(1) - ret) ** 2).sum() / n
+    c_grads = torch.autograd.grad(c_loss, list(critic.parameters()))
+    for net, mode, loss_ref, grads_ref, aux in ((actor, 0, a_loss, a_grads, (actions.float(), old_lp, adv)), (critic, 1, c_loss, c_grads, (ret, None, None))):
+        tr = fused_mlp.FusedMLP(net.layers, lr=1e-3)
+        assert tr.mfma_pass_supported()
+        loss = tr.train_pass(mode, x, aux[0], aux[1], aux[2], count, 0.2)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(float(loss), float(loss_ref), rtol=2e-5, atol=1e-7)
+        for view, ref in zip(tr.views, grads_ref):
+            scale = float(ref.abs().max()) + 1e-12
+            np.testing.assert_allclose(view.cpu().numpy(), ref.cpu().numpy(), rtol=1e-3, atol=2e-5 * scale,
+                                       err_msg="mode %d, gradient of shape %s" % (mode, tuple(ref.shape)))
+        # deterministic: a second launch gives the same bits
+        first = tr.grad.clone()
+        tr.train_pass(mode, x, aux[0], aux[1], aux[2], count, 0.2)
+        assert torch.equal(first, tr.grad)
