@@ -45,7 +45,7 @@ constexpr int H = 128;        // hidden width (the reference's 2 x 128 networks;
 constexpr int HS = 132;       // LDS row stride of the 128-wide images
 constexpr int XS = 36;        // LDS row stride of the 32-wide images
 constexpr int TS = 32;        // samples per tile
-constexpr int kLdsFloats = H * HS + TS * XS + 2 * TS * HS + 4 * TS * 32 + TS * XS + 256 + 8;
+constexpr int kLdsFloats = H * HS + TS * XS + 2 * TS * HS + 4 * TS * 32 + TS * XS + 8;
 
 struct PassArgs {
     const float *params;      // flat: W1[H][S] b1[H] W2[H][H] b2[H] W3[A][H] b3[A]
@@ -64,9 +64,35 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __bu
 __device__ __forceinline__ int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+// float reductions over aligned groups of 8 lanes by DPP (no LDS round trip): xor 1, xor 2 inside the quad, then the
+// mirrored quad of the 8-lane half row.  Every lane of the group ends with the same bits (each step adds / compares
+// the same two values in both lanes: commutative).
+#define FJSP_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
+__device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, FJSP_DPP_F(v, 0xB1));       // quad_perm [1,0,3,2]
+    v = fmaxf(v, FJSP_DPP_F(v, 0x4E));       // quad_perm [2,3,0,1]
+    return fmaxf(v, FJSP_DPP_F(v, 0x141));   // row_half_mirror
+}
+__device__ __forceinline__ float group8_sum(float v) {
+    v = v + FJSP_DPP_F(v, 0xB1);
+    v = v + FJSP_DPP_F(v, 0x4E);
+    return v + FJSP_DPP_F(v, 0x141);
+}
+
+#ifdef FJSP_MLP_STAMPS   // diagnostic build (tools/mlp_phase_stamps.py): cycles per phase of the 3rd tile of workgroup 0, wave 0
+#define STAMP() do { if (tile == (int)blockIdx.x + 2 * (int)gridDim.x && nstamp < 12) stamp[nstamp++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+
 template <int MODE>   // 0: actor (clipped surrogate on softmax logits), 1: critic (mean squared error on the value)
 __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
     extern __shared__ float lds[];
+#ifdef FJSP_MLP_STAMPS
+    const long long k_t0 = __builtin_readcyclecounter(), k_r0 = __builtin_amdgcn_s_memrealtime();
+    long long tile_t[24], stamp[12];
+    int ntile_t = 0, nstamp = 0;
+#endif
     float *W2s = lds;
     float *Xs = W2s + H * HS;
     float *H1s = Xs + TS * XS;
@@ -76,6 +102,7 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
     float *red = dOs + TS * XS;
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, c = l & 31, hf = l >> 5;
+    const int ls = tid >> 3, lg = tid & 7;      // loss stage: sample ls, logits 4 lg .. 4 lg + 3
     const int S = p.S, A = p.A, n = p.n;
     const float *W1 = p.params, *b1 = W1 + H * S, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H, *b3 = W3 + A * H;
     const int col = 32 * w + c;               // the output column / weight row this lane serves
@@ -84,25 +111,28 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
         const f32x4 v = reinterpret_cast<const f32x4 *>(W2)[i];
         *reinterpret_cast<f32x4 *>(&W2s[(i >> 5) * HS + (i & 31) * 4]) = v;
     }
-    // X image: column S = 1 (bias), columns above it 0; rewritten columns 0..S-1 per tile
+    // X image: column S = 1 (bias), columns above it 0; columns 0..S-1 rewritten per tile
     for (int i = tid; i < TS * 32; i += 256) Xs[(i >> 5) * XS + (i & 31)] = ((i & 31) == S) ? 1.0f : 0.0f;
 
     float w1f[16], w3f[16], w3t[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int k = (q >> 2) * 8 + 4 * hf + (q & 3);
-        w1f[q] = k < S ? W1[col * S + k] : (k == S ? b1[col] : 0.0f);           // B[k][o] of G1
-        w3f[q] = c < A ? W3[c * H + 32 * w + k] : 0.0f;                        // B[k = h][a] of G3 (K quarter w)
-        w3t[q] = k < A ? W3[k * H + col] : 0.0f;                               // B[k = a][h] of G5
+        const int k1 = k < S ? col * S + k : (k == S ? H * S + col : -1);     // (b1 follows W1 in the flat buffer)
+        w1f[q] = k1 >= 0 ? W1[k1] : 0.0f;                                     // B[k][o] of G1
+        w3f[q] = c < A ? W3[c * H + 32 * w + k] : 0.0f;                       // B[k = h][a] of G3 (K quarter w)
+        w3t[q] = (MODE == 0 && k < A) ? W3[k * H + col] : 0.0f;               // B[k = a][h] of G5
     }
     const float b2c = b2[col];
     const float b3c = (w == 0 && c < A) ? b3[c] : 0.0f;
+    const float w3c = W3[col];                 // critic: the value head's weight of this column
     const float inv_count = 1.0f / p.count[0];
 
     f32x16 dW2a[4], dW1a, dW3a;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW1a[r] = 0.0f; dW3a[r] = 0.0f; dW2a[0][r] = 0.0f; dW2a[1][r] = 0.0f; dW2a[2][r] = 0.0f; dW2a[3][r] = 0.0f; }
-    float db2a = 0.0f, db3a = 0.0f, loss_a = 0.0f;
+    float db2a = 0.0f, loss_a = 0.0f, dW3c = 0.0f;
+    float db3a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     // this thread's share of a tile's 32*S contiguous input floats
     int xdst[4];
@@ -116,27 +146,24 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
     auto load_x = [&](int tile) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const size_t idx = (size_t)tile * TS * S + tid + 256 * q;
-            xr[q] = (xdst[q] >= 0 && tile < ntiles && idx < (size_t)n * S) ? p.x[idx] : 0.0f;
+            // (unconditional load of a clamped index + select: a load under a branch is followed by a full wait)
+            const size_t idx = (size_t)tile * TS * S + tid + 256 * q, last = (size_t)n * S - 1;
+            const float v = p.x[idx < last ? idx : last];
+            xr[q] = (xdst[q] >= 0 && idx <= last) ? v : 0.0f;
         }
     };
     load_x(blockIdx.x);
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef FJSP_MLP_STAMPS
+        if (ntile_t < 24) tile_t[ntile_t++] = __builtin_readcyclecounter();
+#endif
+        STAMP();
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (xdst[q] >= 0) Xs[xdst[q]] = xr[q];
-        // per-sample loss inputs of the 4 samples this lane's half-wave serves in the loss stage
-        float m0[4], m1[4], m2[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int gs = tile * TS + it * 8 + 2 * w + hf;
-            const bool v = gs < n;
-            m0[it] = v ? p.aux0[gs] : 0.0f;
-            if (MODE == 0) { m1[it] = v ? p.aux1[gs] : 0.0f; m2[it] = v ? p.aux2[gs] : 0.0f; }
-        }
-        load_x(tile + gridDim.x);
         __syncthreads();
+        STAMP();
 
         // ---- G1: H1 = relu([X 1] [W1 b1]^T) ------------------------------------------------------------------
         f32x16 acc;
@@ -148,9 +175,23 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = mfma(a[j], w1f[kc * 4 + j], acc);
         }
+        unsigned mask1 = 0, mask2 = 0;            // bit r: H1 / H2 element (acc_row(r), col) is positive (the ReLU gates of the backward pass)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1s[acc_row(r, hf) * HS + col] = fmaxf(acc[r], 0.0f);
+        for (int r = 0; r < 16; ++r) {
+            mask1 |= (acc[r] > 0.0f ? 1u : 0u) << r;
+            H1s[acc_row(r, hf) * HS + col] = fmaxf(acc[r], 0.0f);
+        }
         __syncthreads();
+        STAMP();
+        // Global loads are issued right after a barrier and land under G2's 64 MFMAs: a barrier waits for every
+        // outstanding memory operation of the wave, a load pending there is a stall of its full latency.
+        const int gs = tile * TS + ls;
+        const bool valid = gs < n;
+        const int gsc = valid ? gs : n - 1;
+        const float m0 = p.aux0[gsc];
+        float m1 = 0.0f, m2 = 0.0f;
+        if (MODE == 0) { m1 = p.aux1[gsc]; m2 = p.aux2[gsc]; }
+        load_x(tile + gridDim.x);
 
         // ---- G2: H2 = relu(H1 W2^T + b2) ---------------------------------------------------------------------
 #pragma unroll
@@ -167,8 +208,12 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H2s[acc_row(r, hf) * HS + col] = fmaxf(acc[r], 0.0f);
+        for (int r = 0; r < 16; ++r) {
+            mask2 |= (acc[r] > 0.0f ? 1u : 0u) << r;
+            H2s[acc_row(r, hf) * HS + col] = fmaxf(acc[r], 0.0f);
+        }
         // (no barrier: G3 reads only the columns this wave has just written)
+        STAMP();
 
         // ---- G3: logits, K quarter w -> OUTp[w] ---------------------------------------------------------------
 #pragma unroll
@@ -182,78 +227,101 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) OUTp[w * (TS * 32) + acc_row(r, hf) * 32 + c] = acc[r];
         __syncthreads();
+        STAMP();
 
-        // ---- loss and d loss / d logits: 32 lanes per sample (lane c = logit c), 8 samples per sweep ----------
+        // ---- loss and d loss / d logits: 8 lanes per sample, 4 logits per lane ------------------------------------
+        if (MODE == 0) {
+            const float *zp = &OUTp[ls * 32 + 4 * lg];
+            const f32x4 z4 = ((ld4(zp) + ld4(zp + TS * 32)) + ld4(zp + 2 * TS * 32)) + ld4(zp + 3 * TS * 32);
+            const int act = (int)m0;
+            const float z_act = ((OUTp[ls * 32 + act] + OUTp[TS * 32 + ls * 32 + act]) + OUTp[2 * TS * 32 + ls * 32 + act]) + OUTp[3 * TS * 32 + ls * 32 + act];
+            float zz[4], e[4];
+            float m = -INFINITY;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int s = it * 8 + 2 * w + hf;
-            const bool valid = tile * TS + s < n;
-            const bool on = valid && c < A;
-            const float z = ((OUTp[s * 32 + c] + OUTp[TS * 32 + s * 32 + c]) + OUTp[2 * TS * 32 + s * 32 + c]) + OUTp[3 * TS * 32 + s * 32 + c];
-            float d = 0.0f;
-            if (MODE == 0) {
-                const float zz = on ? z : -INFINITY;
-                float m = zz;
-                for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-                const float e = on ? expf(zz - m) : 0.0f;
-                float sum = e;
-                for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-                const int act = (int)m0[it];
-                const float z_act = __shfl(zz, (l & 32) + act, 64);
+            for (int i = 0; i < 4; ++i) { zz[i] = (4 * lg + i < A) ? z4[i] : -INFINITY; m = fmaxf(m, zz[i]); }
+            m = group8_max(m);
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { e[i] = (4 * lg + i < A) ? expf(zz[i] - m) : 0.0f; sum += e[i]; }
+            sum = group8_sum(sum);
+            f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (valid) {
+                const float lse = m + logf(sum);
+                const float new_lp = z_act - lse;                                   // log_softmax(...).gather(action), :327-328
+                const float ratio = expf(new_lp) / (expf(m1) + 1e-8f);               // :330-333
+                const float lo = 1.0f - p.clip_eps, hi = 1.0f + p.clip_eps;
+                const float clipped = fminf(fmaxf(ratio, lo), hi);
+                const float s1 = m2 * ratio, s2 = m2 * clipped;                      // :344-350
+                const float inside = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;     // autograd: clamp passes the gradient on [lo, hi],
+                float g;                                                             // minimum splits a tie in half
+                if (s1 < s2) g = m2;
+                else if (s2 < s1) g = m2 * inside;
+                else g = 0.5f * m2 + 0.5f * m2 * inside;
+                const float cf = -g * ratio * inv_count;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = (4 * lg + i < A) ? cf * ((4 * lg + i == act ? 1.0f : 0.0f) - e[i] / sum) : 0.0f;
+                if (lg == 0) loss_a += fminf(s1, s2);
+            }
+            *reinterpret_cast<f32x4 *>(&dOs[ls * XS + 4 * lg]) = d;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) db3a[i] += d[i];
+        } else {
+            if (lg == 0) {
+                const float z = ((OUTp[ls * 32] + OUTp[TS * 32 + ls * 32]) + OUTp[2 * TS * 32 + ls * 32]) + OUTp[3 * TS * 32 + ls * 32];
+                float d = 0.0f;
                 if (valid) {
-                    const float lse = m + logf(sum);
-                    const float new_lp = z_act - lse;                                   // log_softmax(...).gather(action), :327-328
-                    const float ratio = expf(new_lp) / (expf(m1[it]) + 1e-8f);            // :330-333
-                    const float lo = 1.0f - p.clip_eps, hi = 1.0f + p.clip_eps;
-                    const float clipped = fminf(fmaxf(ratio, lo), hi);
-                    const float ad = m2[it];
-                    const float s1 = ad * ratio, s2 = ad * clipped;                      // :344-350
-                    const float inside = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;     // autograd: clamp passes the gradient on [lo, hi],
-                    float g;                                                             // minimum splits a tie in half
-                    if (s1 < s2) g = ad;
-                    else if (s2 < s1) g = ad * inside;
-                    else g = 0.5f * ad + 0.5f * ad * inside;
-                    const float cf = -g * ratio * inv_count;
-                    if (on) d = cf * ((c == act ? 1.0f : 0.0f) - e / sum);
-                    if (c == 0) loss_a += fminf(s1, s2);
-                }
-            } else {
-                if (on) {                                                               // c == 0: the value
-                    const float dv = z - m0[it];
+                    const float dv = z - m0;                                            // F.mse_loss, :317-318
                     d = 2.0f * dv * inv_count;
                     loss_a += dv * dv;
                 }
+                dOs[ls] = d;                                                            // critic: d value [32], contiguous
+                db3a[0] += d;
             }
-            dOs[s * XS + c] = d;
-            db3a += d;
         }
         __syncthreads();
+        STAMP();
 
-        // ---- G4: dW3 += dOUT^T H2 (columns 32w..) ; G5: dH2 = (dOUT W3) * (H2 > 0), in place -------------------
+        if (MODE == 0) {
+            // ---- G4: dW3 += dOUT^T H2 (columns 32w..) ; G5: dH2 = (dOUT W3) * (H2 > 0), in place -------------------
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+            for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int s = kc * 8 + 4 * hf + j;
-                dW3a = mfma(dOs[s * XS + c], H2s[s * HS + col], dW3a);
+                for (int j = 0; j < 4; ++j) {
+                    const int s = kc * 8 + 4 * hf + j;
+                    dW3a = mfma(dOs[s * XS + c], H2s[s * HS + col], dW3a);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const f32x4 a = ld4(&dOs[c * XS + kc * 8 + 4 * hf]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = mfma(a[j], w3t[kc * 4 + j], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ((mask2 >> r) & 1u) ? acc[r] : 0.0f;
+                db2a += v;
+                H2s[acc_row(r, hf) * HS + col] = v;
+            }
+        } else {
+            // critic: one output -> rank-1 products on the vector ALU: dW3[col] += sum_s d[s] H2[s][col]; dH2 = d[s] W3[col] gated
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 d4 = ld4(&dOs[8 * q + 4 * hf]);             // rows acc_row(4q .. 4q+3, hf) = 8q + 4hf + (0..3)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i, idx = acc_row(r, hf) * HS + col;
+                    dW3c = fmaf(d4[i], H2s[idx], dW3c);
+                    const float v = ((mask2 >> r) & 1u) ? d4[i] * w3c : 0.0f;
+                    db2a += v;
+                    H2s[idx] = v;
+                }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const f32x4 a = ld4(&dOs[c * XS + kc * 8 + 4 * hf]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma(a[j], w3t[kc * 4 + j], acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = acc_row(r, hf) * HS + col;
-            const float v = H2s[idx] > 0.0f ? acc[r] : 0.0f;
-            db2a += v;
-            H2s[idx] = v;
-        }
         __syncthreads();
+        STAMP();
 
         // ---- G6: dH1 = (dH2 W2) * (H1 > 0) (kept in registers until G7 has read H1) -----------------------------
         f32x16 dh;
@@ -280,6 +348,7 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
                 for (int j = 0; j < 4; ++j) b[j] = bn[j];
             }
         }
+        STAMP();
         // ---- G7: dW2 += dH2^T H1 (rows 32w..) ---------------------------------------------------------------------
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
@@ -292,12 +361,11 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
             }
         }
         __syncthreads();
+        STAMP();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = acc_row(r, hf) * HS + col;
-            H1s[idx] = H1s[idx] > 0.0f ? dh[r] : 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) H1s[acc_row(r, hf) * HS + col] = ((mask1 >> r) & 1u) ? dh[r] : 0.0f;
         // (no barrier: G8 reads only the columns this wave has just written)
+        STAMP();
 
         // ---- G8: [dW1 db1] += dH1^T [X 1] (rows 32w..) ------------------------------------------------------------
 #pragma unroll
@@ -309,6 +377,7 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
             }
         }
         __syncthreads();
+        STAMP();
     }
 
     // ---- this workgroup's partial gradient, parameter order --------------------------------------------------------
@@ -322,44 +391,77 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
         else if (c == S) ob1[o] = dW1a[r];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) oW2[o * H + 32 * cb + c] = dW2a[cb][r];
-        if (row < A) oW3[row * H + col] = dW3a[r];
+        if (MODE == 0 && row < A) oW3[row * H + col] = dW3a[r];
     }
     const float db2t = db2a + __shfl_xor(db2a, 32, 64);
     if (hf == 0) ob2[col] = db2t;
-    red[(w * 2 + hf) * 32 + c] = db3a;              // 8 sample groups x 32 logits
+    if (MODE == 1) {
+        const float t = dW3c + __shfl_xor(dW3c, 32, 64);
+        if (hf == 0) oW3[col] = t;
+    }
+    float *red4 = H1s;                               // (the activation images are dead) [32 samples][32 logits]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red4[ls * 32 + 4 * lg + i] = db3a[i];
     float lw = loss_a;
     for (int off = 32; off >= 1; off >>= 1) lw += __shfl_xor(lw, off, 64);
-    if (l == 0) red[256 + w] = lw;
+    if (l == 0) red[w] = lw;
     __syncthreads();
     if (tid < A) {
         float s = 0.0f;
-        for (int g = 0; g < 8; ++g) s += red[g * 32 + tid];
+        for (int g = 0; g < TS; ++g) s += red4[g * 32 + tid];
         ob3[tid] = s;
     }
-    if (tid == 0) p.loss_partial[blockIdx.x] = ((red[256] + red[257]) + red[258]) + red[259];
+    if (tid == 0) p.loss_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+#ifdef FJSP_MLP_STAMPS
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {             // (the loss partials of workgroups 16.. are overwritten: diagnostic build)
+        for (int i = 0; i + 1 < nstamp; ++i) p.loss_partial[16 + i] = (float)(stamp[i + 1] - stamp[i]);
+        const long long k_t1 = __builtin_readcyclecounter(), k_r1 = __builtin_amdgcn_s_memrealtime();
+        p.loss_partial[32] = (float)(k_t1 - k_t0);                 // whole kernel, shader cycles
+        p.loss_partial[33] = (float)(k_r1 - k_r0);                 // whole kernel, 100 MHz ticks
+        p.loss_partial[34] = (float)(tile_t[0] - k_t0);            // prologue
+        for (int i = 0; i + 1 < ntile_t; ++i) p.loss_partial[36 + i] = (float)(tile_t[i + 1] - tile_t[i]);
+        p.loss_partial[35] = (float)(k_t1 - tile_t[ntile_t - 1]);  // last tile + epilogue
+    }
+#endif
 }
 
-// grad[j] = sum over the workgroups' partials (fixed order); block = 64 columns x 4 row groups.  Block 0 also
-// finishes the loss: sign * sum / count.
-__global__ __launch_bounds__(256) void grad_finish_kernel(const float *partial, int groups, int numel, float *grad, const float *loss_partial,
+// grad[j] = sum over the workgroups' partials (fixed order); block = 64 columns x 8 row groups, the row loop unrolled
+// so that a thread's loads are all in flight together.  Block 0 also finishes the loss: sign * sum / count.
+__global__ __launch_bounds__(512) void grad_finish_kernel(const float *partial, int groups, int numel, float *grad, const float *loss_partial,
                                                           const float *count, float sign, float *loss) {
-    __shared__ float sh[256];
+    __shared__ float sh[512];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cl;
     float s = 0.0f;
-    if (j < numel) for (int g = rg; g < groups; g += 4) s += partial[(size_t)g * numel + j];
+    if (j < numel) {
+        int g = rg;
+        for (; g + 56 < groups; g += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + 8 * u) * numel + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < groups; g += 8) s += partial[(size_t)g * numel + j];
+    }
     sh[threadIdx.x] = s;
     __syncthreads();
-    if (rg == 0 && j < numel) grad[j] = ((sh[cl] + sh[64 + cl]) + sh[128 + cl]) + sh[192 + cl];
+    if (rg == 0 && j < numel) {
+        float t = sh[cl];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sh[64 * q + cl];
+        grad[j] = t;
+    }
     if (blockIdx.x == 0) {
         __syncthreads();
         float v = 0.0f;
-        for (int g = threadIdx.x; g < groups; g += 256) v += loss_partial[g];
+        for (int g = threadIdx.x; g < groups; g += 512) v += loss_partial[g];
         sh[threadIdx.x] = v;
         __syncthreads();
         if (threadIdx.x == 0) {
             float t = 0.0f;
-            for (int i = 0; i < 256; ++i) t += sh[i];
+            for (int i = 0; i < 512; ++i) t += sh[i];
             loss[0] = sign * t / count[0];
         }
     }
@@ -411,7 +513,7 @@ int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, i
     a.n = n; a.S = state_size; a.A = n_out; a.numel = H * state_size + H + H * H + H + n_out * H + n_out; a.clip_eps = clip_epsilon;
     if (mode == 0) hipLaunchKernelGGL(mlp_train_pass_kernel<0>, dim3(groups), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mlp_train_pass_kernel<1>, dim3(groups), dim3(256), lds, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(grad_finish_kernel, dim3((a.numel + 63) / 64), dim3(256), 0, (hipStream_t)stream, d_partial, groups, a.numel, d_grad,
+    hipLaunchKernelGGL(grad_finish_kernel, dim3((a.numel + 63) / 64), dim3(512), 0, (hipStream_t)stream, d_partial, groups, a.numel, d_grad,
                        d_loss_partial, d_count, mode == 0 ? -1.0f : 1.0f, d_loss);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fjsp::set_error(std::string("fjsp_mlp_train_pass: ") + hipGetErrorString(e)); return FJSP_E_HIP; }
