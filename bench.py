@@ -39,12 +39,13 @@ REFERENCE_PYTHON_STEPS_PER_S = 1700.0
 
 
 def csrc_hash():
-    """sha256 over the kernel sources: ties a committed PMC figure to the code it was measured on."""
+    """sha256 over the sources the environment kernels are compiled from: ties a committed PMC figure to the code it
+    was measured on (the learner's kernels -- fjsp_ppo.hip, fjsp_mlp_train.hip -- are not part of the measured launch)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(REPO, "deep_reinforcement_learning_for_fjsp_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h", ".cpp")) and f not in ("fjsp_ppo.hip", "fjsp_mlp_train.hip"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
