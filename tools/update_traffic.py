@@ -5,7 +5,7 @@ kernel sources it was measured on (bench.py drops the figure when the sources ha
 fused kernel's instruction count per wave-step for its issue roofline.
 
 FETCH_SIZE correction: rocprofv3 reports FETCH_SIZE in KiB; on gfx950 it counts HALF the bytes of coalesced row
-reads at 4, 8 and 16 bytes per lane alike (tools/fetch_calib.sh, profiles/r02_fetch_calibration.json: reported /
+reads at 4, 8 and 16 bytes per lane alike (tools/fetch_calib.sh, profiles/r02_r_fetch_calibration.json: reported /
 true = 0.5000 for all three), so it is doubled.  WRITE_SIZE is taken as reported."""
 import json
 import os
@@ -35,7 +35,7 @@ out = {
     "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip(),
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh), per-dispatch means over "
             "%d dispatches; FETCH_SIZE doubled (gfx950 counts half the bytes of coalesced 4/8/16 B-per-lane row reads: "
-            "profiles/r02_fetch_calibration.json), WRITE_SIZE as reported; the working set (~85 MB) sits in the 256 MB Infinity "
+            "profiles/r02_r_fetch_calibration.json), WRITE_SIZE as reported; the working set (~85 MB) sits in the 256 MB Infinity "
             "Cache, whose hits these fabric-side counters include" % sk.get("dispatches_pmc_fetch", 0),
     "insts_per_wave_step": {k: sk[k] / sk["SQ_WAVES"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
                                                                 "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if k in sk},
