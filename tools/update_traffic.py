@@ -35,8 +35,8 @@ out = {
     "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip(),
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_bench.sh), per-dispatch means over "
             "%d dispatches; FETCH_SIZE doubled (gfx950 counts half the bytes of coalesced 4/8/16 B-per-lane row reads: "
-            "profiles/r02_r_fetch_calibration.json), WRITE_SIZE as reported; the working set (~85 MB) sits in the 256 MB Infinity "
-            "Cache, whose hits these fabric-side counters include" % sk.get("dispatches_pmc_fetch", 0),
+            "profiles/r02_r_fetch_calibration.json), WRITE_SIZE as reported; the ~18 MB a launch touches stay in the 256 MB "
+            "Infinity Cache between launches, whose hits these fabric-side counters include" % sk.get("dispatches_pmc_fetch", 0),
     "insts_per_wave_step": {k: sk[k] / sk["SQ_WAVES"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
                                                                 "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if k in sk},
 }
