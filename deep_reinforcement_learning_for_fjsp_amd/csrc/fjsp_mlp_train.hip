@@ -118,10 +118,11 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int k = (q >> 2) * 8 + 4 * hf + (q & 3);
+        // (loads of clamped indices times a 0/1 factor: branch-free, so the 48 loads are in flight together)
         const int k1 = k < S ? col * S + k : (k == S ? H * S + col : -1);     // (b1 follows W1 in the flat buffer)
-        w1f[q] = k1 >= 0 ? W1[k1] : 0.0f;                                     // B[k][o] of G1
-        w3f[q] = c < A ? W3[c * H + 32 * w + k] : 0.0f;                       // B[k = h][a] of G3 (K quarter w)
-        w3t[q] = (MODE == 0 && k < A) ? W3[k * H + col] : 0.0f;               // B[k = a][h] of G5
+        w1f[q] = W1[k1 >= 0 ? k1 : 0] * (k1 >= 0 ? 1.0f : 0.0f);              // B[k][o] of G1
+        w3f[q] = W3[(c < A ? c : 0) * H + 32 * w + k] * (c < A ? 1.0f : 0.0f);   // B[k = h][a] of G3 (K quarter w)
+        w3t[q] = MODE == 0 ? W3[(k < A ? k : 0) * H + col] * (k < A ? 1.0f : 0.0f) : 0.0f;   // B[k = a][h] of G5
     }
     const float b2c = b2[col];
     const float b3c = (w == 0 && c < A) ? b3[c] : 0.0f;
@@ -146,10 +147,11 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
     auto load_x = [&](int tile) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // (unconditional load of a clamped index + select: a load under a branch is followed by a full wait)
+            // Unconditional load of a clamped index, no select: a load under a branch is followed by a full wait.  Lanes
+            // without a share never store their value; rows beyond n get finite data of the last rows, and their
+            // d logits are 0, so they add exact zeros to every gradient.
             const size_t idx = (size_t)tile * TS * S + tid + 256 * q, last = (size_t)n * S - 1;
-            const float v = p.x[idx < last ? idx : last];
-            xr[q] = (xdst[q] >= 0 && idx <= last) ? v : 0.0f;
+            xr[q] = p.x[idx < last ? idx : last];
         }
     };
     load_x(blockIdx.x);
