@@ -57,7 +57,7 @@ def produce_action_and_action_info(actor, state):
     """:265-275"""
     action_probabilities = actor(state)
     max_probability_action = torch.argmax(action_probabilities, dim=-1)
-    action = Categorical(action_probabilities).sample()
+    action = Categorical(action_probabilities, validate_args=False).sample()      # (the validation syncs with the host)
     z = (action_probabilities == 0.0).float() * 1e-8
     log_action_probabilities = torch.log(action_probabilities + z)
     return action, (action_probabilities, log_action_probabilities), max_probability_action
@@ -110,16 +110,17 @@ class SAC_Discrete(Base_Agent, Config):
         self.actor_local = mk(PolicyNet, 3)
         torch.random.set_rng_state(rng)
         lr = hp["learning_rate"]
-        self.critic_optimizer = Adam(self.critic_local.parameters(), lr=lr, eps=1e-4)
-        self.critic_optimizer_2 = Adam(self.critic_local_2.parameters(), lr=lr, eps=1e-4)
-        self.actor_optimizer = Adam(self.actor_local.parameters(), lr=lr, eps=1e-4)
+        cap = self.device.type == "cuda"       # step counts on the device: the update is replayed from a captured graph
+        self.critic_optimizer = Adam(self.critic_local.parameters(), lr=lr, eps=1e-4, capturable=cap)
+        self.critic_optimizer_2 = Adam(self.critic_local_2.parameters(), lr=lr, eps=1e-4, capturable=cap)
+        self.actor_optimizer = Adam(self.actor_local.parameters(), lr=lr, eps=1e-4, capturable=cap)
         self.memory = DeviceReplayBuffer(hp["buffer_size"], hp["batch_size"], self.state_size, self.device, seed=seed)
         self.automatic_entropy_tuning = hp["automatically_tune_entropy_hyper_parameter"]
         if self.automatic_entropy_tuning:
             self.target_entropy = -np.log((1.0 / self.action_size)) * 0.98                 # :166
             self.log_alpha = torch.zeros(1, requires_grad=True, device=self.device)
-            self.alpha = self.log_alpha.exp()
-            self.alpha_optim = Adam([self.log_alpha], lr=lr, eps=1e-4)
+            self.alpha = self.log_alpha.exp().detach()
+            self.alpha_optim = Adam([self.log_alpha], lr=lr, eps=1e-4, capturable=cap)
         else:
             self.alpha = hp["entropy_term_weight"]
         self.buckets = {n: fdist.FlatGradBucket(n.parameters()) for n in (self.critic_local, self.critic_local_2, self.actor_local)}
@@ -136,6 +137,8 @@ class SAC_Discrete(Base_Agent, Config):
         self._next_learn = hp["update_every_n_steps"]
         self.learn_sessions = 0
         self._last_losses = None
+        self.use_graph = True            # replay the per-step device work and the update from captured HIP graphs (GPU only)
+        self._graphs, self._static, self._learn_graph = {}, None, None
 
     @property
     def last_losses(self):
@@ -181,6 +184,52 @@ class SAC_Discrete(Base_Agent, Config):
         action, _, _ = produce_action_and_action_info(self.actor_local, state.float())
         return action
 
+    # -- a vector step's device work outside the environment, replayed from two captured HIP graphs -------------
+    def _step_graphs(self, which, random_phase):
+        """(act, store) graphs for one kind of episode.  `act` turns the static state / done tensors into the action
+        pair (controller: controller action first); `store` runs after env.step(): replay-buffer rows of the live
+        envs (controller episodes), then next state / done into the static tensors.  A vector step is then two graph
+        launches and the environment call instead of ~60 small launches (policy MLPs, Categorical, prefix sum and
+        scatter of the replay rows), whose host cost was ~10x their device time."""
+        key = (which, random_phase)
+        g = self._graphs.get(key)
+        if g is not None:
+            return g
+        env, st = self.environment, self._static
+        eb = env.batch
+
+        def act():
+            st["active"].copy_(st["done"] == 0)
+            if which is None:
+                st["action"].copy_(self.pick_action(st["state"]))
+                st["pair"].copy_(self.pick_lower_action(st["action"], st["state"]))
+            else:
+                st["pair"].copy_(self.pick_lower_action(which, st["state"]))
+
+        def store():
+            if which is None:
+                self.memory.add_batch(st["state"], st["action"], eb.reward, eb.state, eb.done, st["active"])
+                st["played"].add_(st["active"].sum())
+            st["state"].copy_(eb.state)
+            st["done"].copy_(eb.done)
+
+        keep = {k: v.clone() for k, v in st.items()}
+        mem = self.memory.snapshot_cursor() if which is None else None
+        st["done"].fill_(1)                               # warm-up with no live env: nothing reaches the replay ring
+        act(); store()                                    # (outside the capture: allocator, library handles)
+        torch.cuda.synchronize(self.device)
+        ga, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, capture_error_mode="relaxed"):
+            act()
+        with torch.cuda.graph(gs, capture_error_mode="relaxed"):
+            store()
+        for k, v in keep.items():                         # the warm-up ran on stale env outputs: undo what it changed
+            st[k].copy_(v)
+        if mem is not None:
+            self.memory.restore_cursor(mem)
+        g = self._graphs[key] = (ga, gs)
+        return g
+
     def _episode(self, which=None, objectives=None):
         """One episode of every environment.  which = lower policy index (baseline episodes, reward_policy 0)
         or None (controller episode, reward_policy 3 normalised by `objectives` [N, 3])."""
@@ -189,21 +238,45 @@ class SAC_Discrete(Base_Agent, Config):
             env.set_objective(3, objectives[:, 0], objectives[:, 1], objectives[:, 2])
         else:
             env.set_objective(0)
+        graphed = self.use_graph and self.device.type == "cuda"
+        if graphed and self._static is None:
+            N = env.N
+            self._static = dict(state=torch.zeros(N, self.state_size, dtype=torch.float64, device=self.device),
+                                done=torch.zeros(N, dtype=torch.uint8, device=self.device),
+                                active=torch.zeros(N, dtype=torch.bool, device=self.device),
+                                action=torch.zeros(N, dtype=torch.int64, device=self.device),
+                                pair=torch.zeros(N, 2, dtype=torch.uint8, device=self.device),
+                                played=torch.zeros((), dtype=torch.int64, device=self.device))
         state = env.reset().clone()
         done = torch.zeros(env.N, dtype=torch.uint8, device=self.device)
         played = torch.zeros((), dtype=torch.int64, device=self.device)     # transitions since the last host visit
+        if graphed:
+            st = self._static
+            st["state"].copy_(state); st["done"].zero_(); st["played"].zero_()
+            played = st["played"]
         for t in range(self.max_steps):
-            active = done == 0
-            if which is None:
-                action = self.pick_action(state)
-                pair = self.pick_lower_action(action, state)
+            if graphed:
+                random_phase = which is None and self.global_step_number < hp["min_steps_before_learning"]
+                ga, gs = self._step_graphs(which, random_phase)
+                ga.replay()
+                if which is None:
+                    env.step(st["pair"])
+                    gs.replay()
+                else:                                            # baseline episodes store nothing: the environment writes
+                    env.batch.step(st["pair"], mo=env.mo, state_out=st["state"], done_out=st["done"])   # the static tensors itself
+                done = st["done"]
             else:
-                pair = self.pick_lower_action(which, state)
-            nxt, rew, dn = env.step(pair)
-            if which is None:
-                self.memory.add_batch(state, action, rew, nxt, dn, active)
-                played += active.sum()
-            state, done = nxt.clone(), dn.clone()
+                active = done == 0
+                if which is None:
+                    action = self.pick_action(state)
+                    pair = self.pick_lower_action(action, state)
+                else:
+                    pair = self.pick_lower_action(which, state)
+                nxt, rew, dn = env.step(pair)
+                if which is None:
+                    self.memory.add_batch(state, action, rew, nxt, dn, active)
+                    played += active.sum()
+                state, done = nxt.clone(), dn.clone()
             if t % 16 == 15:                                     # one host round trip per 16 vector steps
                 if which is None:
                     self.global_step_number += int(played.item())
@@ -216,6 +289,7 @@ class SAC_Discrete(Base_Agent, Config):
                     break
         if which is None:
             self.global_step_number += int(played.item())
+            played.zero_()
         r = env.read()
         return torch.stack([r["completion_time"].double(), r["delay_time_sum"].double(), r["energy_consumption"].double()], 1)
 
@@ -256,9 +330,31 @@ class SAC_Discrete(Base_Agent, Config):
         optimizer.step()
 
     def learn(self):
-        """:293-306,335-352"""
-        hp = self.hyper_parameters
+        """:293-306,335-352.  On the GPU the update (three losses, four backward passes, four Adam steps, two soft target
+        updates: ~300 small launches, 6 ms of host time for 0.5 ms of device work) is captured once into a HIP graph and
+        replayed on static copies of the sampled batch; sampling itself stays outside (its size is a host value)."""
         batch = self.memory.sample()
+        if not (self.use_graph and self.device.type == "cuda" and not fdist.is_distributed()):
+            return self._learn_body(batch)
+        g = self._learn_graph
+        if g is None:                                   # first update: eager (creates the optimiser state the capture needs)
+            self._learn_graph = {"graph": None}
+            return self._learn_body(batch)
+        if g["graph"] is None:
+            g["in"] = tuple(t.clone() for t in batch)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                g["out"] = self._learn_body(g["in"])
+            g["graph"] = graph
+        for dst, src in zip(g["in"], batch):
+            dst.copy_(src)
+        g["graph"].replay()
+        self._last_losses = g["out"]
+        return self._last_losses
+
+    def _learn_body(self, batch):
+        hp = self.hyper_parameters
         alpha = self.alpha.detach() if torch.is_tensor(self.alpha) else self.alpha
         qf1_loss, qf2_loss = sac_critic_losses(self.actor_local, self.critic_local, self.critic_local_2, self.critic_target,
                                                self.critic_target_2, alpha, batch, hp["discount_rate"])
@@ -276,6 +372,7 @@ class SAC_Discrete(Base_Agent, Config):
                 torch.distributed.all_reduce(self.log_alpha.grad)
                 self.log_alpha.grad /= fdist.world_size()
             self.alpha_optim.step()
-            self.alpha = self.log_alpha.exp()
+            with torch.no_grad():
+                self.alpha.copy_(self.log_alpha.exp())    # (in place: a captured graph keeps reading this tensor)
         self._last_losses = (qf1_loss.detach(), qf2_loss.detach(), policy_loss.detach())     # read lazily: no sync here
         return self._last_losses

@@ -80,6 +80,14 @@ class DeviceReplayBuffer(object):
         self._head.copy_((self._head + n_live) % self.capacity)
         self._size.copy_(torch.clamp(self._size + n_live, max=self.capacity))
 
+    def snapshot_cursor(self):
+        """(head, size) as they are now; with restore_cursor() lets a caller undo appended rows (graph warm-ups)."""
+        return self._head.clone(), self._size.clone()
+
+    def restore_cursor(self, cursor):
+        self._head.copy_(cursor[0])
+        self._size.copy_(cursor[1])
+
     def add_experience(self, states, actions, rewards, next_states, dones):
         """Single-transition form of the reference's method (host values)."""
         t = lambda v, w: torch.as_tensor(np.asarray(v, dtype=np.float32).reshape(1, w), device=self.device)
