@@ -7,6 +7,11 @@ layers on the library GEMMs (MFMA, bias / ReLU in the GEMM epilogue) and does th
 kernels (csrc/fjsp_ppo.hip): loss + its gradient in one pass, ReLU backward + bias gradient in one pass, gradient
 clipping + Adam in one pass over ONE flat parameter buffer (which is also the single all-reduce bucket of SURVEY 8e).
 
+`train_pass()` goes one step further for the reference's shapes (128 hidden units, <= 31 state features, <= 32
+outputs): forward + loss + backward in ONE launch on the f32 matrix cores with the activations resident in LDS
+(csrc/fjsp_mlp_train.hip; 2.1x the library-GEMM pass).  forward() / *_loss() / backward() remain for other shapes and
+for the forward-only advantage pass.
+
 The parameters stay the `nn.Parameter`s of the wrapped module -- re-homed as views of the flat buffer -- so
 everything else (acting, checkpoints, equalise_policies, the in-kernel actor of the fused rollout) sees them as before.
 """

@@ -19,7 +19,8 @@ names = {
     "bench_mo_dfjsp_async.json": "bench_mo_dfjsp_async.json", "bench_training_distribution.json": "bench_training_distribution.json",
     "train_ppo.json": "train_ppo.json", "train_ppo_per_step_rollout.json": "train_ppo_per_step_rollout.json",
     "ppo_round_split.txt": "ppo_round_split.txt", "ppo_round_kernel_stats.csv": "ppo_round_rocprofv3_kernel_stats.csv",
-    "host_overhead.txt": "host_overhead.txt",
+    "host_overhead.txt": "host_overhead.txt", "train_hmpsac.json": "train_hmpsac.json", "hmpsac_epoch_split.txt": "hmpsac_epoch_split.txt",
+    "mlp_pass_timing.txt": "mlp_pass_timing.txt",
 }
 for a, b in names.items():
     p = os.path.join(src, a)

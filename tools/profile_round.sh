@@ -34,4 +34,7 @@ with open(sys.argv[1] + "/ppo_round_kernel_stats.csv", "w", newline="") as fh:
     w.writerows(rows[:60])
 PY
 python3 $ROOT/tools/host_overhead.py 8 > $OUT/host_overhead.txt 2>&1
+python3 $ROOT/examples/train_hmpsac.py --envs 4096 --lower-envs 256 --lower-rounds 2 --epochs 1 > $OUT/train_hmpsac.json 2> $OUT/train_hmpsac.err
+python3 $ROOT/tools/time_hmpsac_epoch.py > $OUT/hmpsac_epoch_split.txt 2>&1
+python3 $ROOT/tools/time_mlp_pass.py > $OUT/mlp_pass_timing.txt 2>&1
 echo done
