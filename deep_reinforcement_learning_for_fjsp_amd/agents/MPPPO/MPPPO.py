@@ -270,8 +270,16 @@ class PPOLearner(object):
         c_loss = a_loss = None
         one_launch = self.mfma_learn and actor.mfma_pass_supported() and critic.mfma_pass_supported()
         for _ in range(hp["learning_iterations_per_round_critic"]):
+            if one_launch and reduce is None:
+                # forward, loss, backward, clip + Adam of a network in three launches (single process: no all-reduce between)
+                if self.train_critic:
+                    c_loss = critic.train_step(1, states, returns, None, None, count)                       # F.mse_loss, :318
+                else:
+                    c_loss = critic.train_pass(1, states, returns, None, None, count)
+                a_loss = actor.train_step(0, states, actions_f, old_log_prob, advantages, count, hp["clip_epsilon"])   # :325-352
+                continue
             if one_launch:
-                c_loss = critic.train_pass(1, states, returns, None, None, count)                 # forward, F.mse_loss (:318), backward
+                c_loss = critic.train_pass(1, states, returns, None, None, count)
             else:
                 critic.forward(states)
                 c_loss = critic.critic_loss(returns, count)
@@ -280,7 +288,7 @@ class PPOLearner(object):
             if self.train_critic:
                 critic.step(reduce)
             if one_launch:
-                a_loss = actor.train_pass(0, states, actions_f, old_log_prob, advantages, count, hp["clip_epsilon"])   # :325-352
+                a_loss = actor.train_pass(0, states, actions_f, old_log_prob, advantages, count, hp["clip_epsilon"])
             else:
                 actor.forward(states)
                 a_loss = actor.actor_loss(actions_f, old_log_prob, advantages, hp["clip_epsilon"], count)

@@ -149,21 +149,40 @@ class FusedMLP(object):
         """The one-launch training pass covers the reference's shapes: 128 hidden units, <= 31 state features, <= 32 outputs."""
         return self.H == 128 and self.lin[0].in_features <= 31 and self.out <= 32
 
-    @torch.no_grad()
-    def train_pass(self, mode, x, aux0, aux1, aux2, count, clip_epsilon=0.0):
-        """mode 0: actor (aux = actions f32, old log-probabilities, advantages); mode 1: critic (aux0 = returns).
-        Fills the flat gradient buffer and returns the loss (f32[1])."""
-        n = x.shape[0]
+    def train_pass_buffers(self, n):
         key = ("pass", n)
         b = self._buf.get(key)
         if b is None:
             groups = self._lib.fjsp_mlp_train_groups(n)
             f = dict(dtype=torch.float32, device=self.device)
-            b = dict(groups=groups, partial=torch.empty(groups, self.numel, **f), loss_partial=torch.empty(groups, **f), loss=torch.zeros(1, **f))
+            b = dict(groups=groups, partial=torch.empty(groups, self.numel, **f), loss_partial=torch.empty(groups, **f), loss=torch.zeros(1, **f),
+                     sumsq=torch.zeros((self.numel + 63) // 64, **f))
             self._buf[key] = b
+        return b
+
+    @torch.no_grad()
+    def train_pass(self, mode, x, aux0, aux1, aux2, count, clip_epsilon=0.0):
+        """mode 0: actor (aux = actions f32, old log-probabilities, advantages); mode 1: critic (aux0 = returns).
+        Fills the flat gradient buffer and returns the loss (f32[1])."""
+        n = x.shape[0]
+        b = self.train_pass_buffers(n)
         _capi.check(self._lib.fjsp_mlp_train_pass(int(mode), _p(self.flat), _p(x), n, self.lin[0].in_features, self.H, self.out, _p(aux0), _p(aux1),
                                                   _p(aux2), _p(count), float(clip_epsilon), _p(b["partial"]), b["groups"], _p(b["loss_partial"]),
                                                   _p(self.grad), _p(b["loss"]), self._stream()))
+        return b["loss"]
+
+    @torch.no_grad()
+    def train_step(self, mode, x, aux0, aux1, aux2, count, clip_epsilon=0.0):
+        """train_pass() + step() of a single process in three launches (fjsp_mlp_train_step): the gradient finish also
+        produces the squared norm for the clip and advances the step count."""
+        n = x.shape[0]
+        self.train_pass_buffers(n)
+        b = self._buf[("pass", n)]
+        _capi.check(self._lib.fjsp_mlp_train_step(int(mode), _p(self.flat), _p(x), n, self.lin[0].in_features, self.H, self.out, _p(aux0),
+                                                  _p(aux1), _p(aux2), _p(count), float(clip_epsilon), _p(b["partial"]), b["groups"],
+                                                  _p(b["loss_partial"]), _p(self.grad), _p(b["loss"]), _p(self.exp_avg), _p(self.exp_avg_sq),
+                                                  self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps, _p(self.step_count),
+                                                  _p(b["sumsq"]), self._stream()))
         return b["loss"]
 
     # -- optimiser step --------------------------------------------------------------------------------------------

@@ -41,6 +41,7 @@
 // spills ~150 registers (the six 16-register accumulators plus fragments), and every reload waits for memory.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -443,8 +444,11 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
 
 // grad[j] = sum over the workgroups' partials (fixed order); block = 64 columns x 8 row groups, the row loop unrolled
 // so that a thread's loads are all in flight together.  Block 0 also finishes the loss: sign * sum / count.
+// With sumsq_partial != nullptr (the single-process optimiser step that follows in the same stream): also
+// sumsq_partial[block] = sum of the squares of the block's 64 gradient entries (clip_grad_norm_'s total norm), and
+// block 0 advances the optimiser's step count.
 __global__ __launch_bounds__(512) void grad_finish_kernel(const float *partial, int groups, int numel, float *grad, const float *loss_partial,
-                                                          const float *count, float sign, float *loss) {
+                                                          const float *count, float sign, float *loss, float *sumsq_partial, float *step) {
     __shared__ float sh[512];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cl;
@@ -467,6 +471,16 @@ __global__ __launch_bounds__(512) void grad_finish_kernel(const float *partial, 
 #pragma unroll
         for (int q = 1; q < 8; ++q) t += sh[64 * q + cl];
         grad[j] = t;
+        s = t * t;
+    } else {
+        s = 0.0f;
+    }
+    if (sumsq_partial) {                              // (rg == 0 is wave 0: its 64 lanes hold the block's squares)
+        if (rg == 0) {
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (cl == 0) sumsq_partial[blockIdx.x] = s;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) step[0] += 1.0f;
     }
     if (blockIdx.x == 0) {
         __syncthreads();
@@ -479,6 +493,40 @@ __global__ __launch_bounds__(512) void grad_finish_kernel(const float *partial, 
             for (int i = 0; i < 512; ++i) t += sh[i];
             loss[0] = sign * t / count[0];
         }
+    }
+}
+
+// clip_grad_norm_ (coefficient from the finish kernel's partial sums of squares) + Adam (torch.optim.Adam, no weight
+// decay, no amsgrad); *step is the count AFTER this step (advanced by the finish kernel).  Same arithmetic as
+// adam_clip_kernel of fjsp_ppo.hip.
+__global__ __launch_bounds__(256) void adam_apply_kernel(float *p, const float *g, float *m, float *v, int n, const float *sumsq_partial, int nparts,
+                                                         float max_norm, float lr, float beta1, float beta2, float eps, const float *step) {
+    __shared__ float sh[256];
+    __shared__ float coef_s, bc1_s, bc2_s;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < nparts; i += 256) ss += sumsq_partial[i];
+    sh[threadIdx.x] = ss;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = sqrtf(sh[0]);
+        coef_s = max_norm > 0.0f ? fminf(max_norm / (total + 1e-6f), 1.0f) : 1.0f;
+        const float t = step[0];
+        bc1_s = 1.0f - powf(beta1, t);
+        bc2_s = 1.0f - powf(beta2, t);
+    }
+    __syncthreads();
+    const float coef = coef_s, bc1 = bc1_s, bc2 = bc2_s;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
     }
 }
 
@@ -500,10 +548,11 @@ int fjsp_mlp_train_groups(int32_t n) {
     return tiles < g_groups ? (tiles > 0 ? tiles : 1) : g_groups;
 }
 
-int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden,
-                        int32_t n_out, const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count,
-                        float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss,
-                        void *stream) {
+namespace {
+int train_pass_launch(int32_t mode, const float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
+                      const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon, float *d_partial,
+                      int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_sumsq_partial, float *d_step, void *stream,
+                      int *numel_out) {
     if (!d_params || !d_x || !d_aux0 || !d_count || !d_partial || !d_loss_partial || !d_grad || !d_loss || n <= 0 ||
         (mode != 0 && mode != 1) || (mode == 0 && (!d_aux1 || !d_aux2))) {
         fjsp::set_error("fjsp_mlp_train_pass: bad arguments"); return FJSP_E_ARG;
@@ -529,9 +578,40 @@ int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, i
     if (mode == 0) hipLaunchKernelGGL(mlp_train_pass_kernel<0>, dim3(groups), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mlp_train_pass_kernel<1>, dim3(groups), dim3(256), lds, (hipStream_t)stream, a);
     hipLaunchKernelGGL(grad_finish_kernel, dim3((a.numel + 63) / 64), dim3(512), 0, (hipStream_t)stream, d_partial, groups, a.numel, d_grad,
-                       d_loss_partial, d_count, mode == 0 ? -1.0f : 1.0f, d_loss);
+                       d_loss_partial, d_count, mode == 0 ? -1.0f : 1.0f, d_loss, d_sumsq_partial, d_step);
+    *numel_out = a.numel;
+    return FJSP_OK;
+}
+}  // namespace
+
+int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden,
+                        int32_t n_out, const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count,
+                        float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss,
+                        void *stream) {
+    int numel = 0;
+    const int rc = train_pass_launch(mode, d_params, d_x, n, state_size, hidden, n_out, d_aux0, d_aux1, d_aux2, d_count, clip_epsilon, d_partial,
+                                     n_groups, d_loss_partial, d_grad, d_loss, nullptr, nullptr, stream, &numel);
+    if (rc != FJSP_OK) return rc;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fjsp::set_error(std::string("fjsp_mlp_train_pass: ") + hipGetErrorString(e)); return FJSP_E_HIP; }
+    return FJSP_OK;
+}
+
+int fjsp_mlp_train_step(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
+                        const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon,
+                        float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_exp_avg,
+                        float *d_exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, float *d_step,
+                        float *d_sumsq_partial, void *stream) {
+    if (!d_exp_avg || !d_exp_avg_sq || !d_step || !d_sumsq_partial) { fjsp::set_error("fjsp_mlp_train_step: bad arguments"); return FJSP_E_ARG; }
+    int numel = 0;
+    const int rc = train_pass_launch(mode, d_params, d_x, n, state_size, hidden, n_out, d_aux0, d_aux1, d_aux2, d_count, clip_epsilon, d_partial,
+                                     n_groups, d_loss_partial, d_grad, d_loss, d_sumsq_partial, d_step, stream, &numel);
+    if (rc != FJSP_OK) return rc;
+    const int blocks = std::min(256, (numel + 255) / 256);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_params, d_grad, d_exp_avg, d_exp_avg_sq, numel,
+                       d_sumsq_partial, (numel + 63) / 64, max_norm, lr, beta1, beta2, eps, d_step);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fjsp::set_error(std::string("fjsp_mlp_train_step: ") + hipGetErrorString(e)); return FJSP_E_HIP; }
     return FJSP_OK;
 }
 

@@ -335,8 +335,16 @@ int fjsp_adam_clip_step(float *d_params, const float *d_grads, float *d_exp_avg,
  * advantages; loss and gradient as fjsp_ppo_actor_loss.  mode 1 (critic, n_out == 1): d_aux0 = returns; loss as
  * fjsp_ppo_critic_loss.  Outputs: d_grad f32[numel] = d loss / d params (same order as d_params), *d_loss.
  * Scratch: d_partial f32[n_groups][numel], d_loss_partial f32[n_groups], n_groups = fjsp_mlp_train_groups(n).
- * FJSP_E_UNSUPPORTED unless state_size <= 31, hidden == 128, n_out <= 32. */
+ * FJSP_E_UNSUPPORTED unless state_size <= 31, hidden == 128, n_out <= 32.
+ * fjsp_mlp_train_step: the pass followed by the optimiser step of fjsp_adam_clip_step on d_grad, in three launches
+ * (pass, gradient finish + squared norm + step count, clip + Adam); d_sumsq_partial: f32 scratch of (numel + 63) / 64
+ * entries.  Single-process form: with several GPUs call fjsp_mlp_train_pass, all-reduce d_grad, fjsp_adam_clip_step. */
 int fjsp_mlp_train_groups(int32_t n);
+int fjsp_mlp_train_step(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
+                        const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon,
+                        float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_exp_avg,
+                        float *d_exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, float *d_step,
+                        float *d_sumsq_partial, void *stream);
 int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden,
                         int32_t n_out, const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count,
                         float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss,

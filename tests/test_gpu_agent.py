@@ -529,3 +529,36 @@ def test_one_launch_training_pass_matches_autograd(torch_gpu, n, S, A):
         first = tr.grad.clone()
         tr.train_pass(mode, x, aux[0], aux[1], aux[2], count, 0.2)
         assert torch.equal(first, tr.grad)
+
+
+@pytest.mark.gpu
+def test_train_step_equals_pass_plus_optimiser_step(torch_gpu):
+    """fjsp_mlp_train_step (pass, gradient finish + squared norm + step count, clip + Adam: three launches) against
+    train_pass() followed by the separate fjsp_adam_clip_step, two steps on the same weights and samples: identical
+    gradients, parameters equal up to the summation order of the clip norm."""
+    torch = torch_gpu
+    import copy
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO import MPPPO as M
+    from deep_reinforcement_learning_for_fjsp_amd.agents import fused_mlp
+    dev = torch.device("cuda", 0)
+    n, S, A = 5000, 20, 24
+    g = torch.Generator(device="cuda").manual_seed(11)
+    torch.manual_seed(5)
+    net_a = M.ActorNet(S, 128, 2, A).to(dev)
+    net_b = copy.deepcopy(net_a)
+    x = torch.randn(n, S, device=dev, generator=g)
+    actions = torch.randint(0, A, (n,), device=dev, generator=g).float()
+    old_lp = -torch.rand(n, device=dev, generator=g) * 3 - 0.2
+    adv = torch.randn(n, device=dev, generator=g) * 50.0            # large advantages: the clip coefficient is < 1
+    count = torch.full((1,), float(n), device=dev)
+    ta, tb = fused_mlp.FusedMLP(net_a.layers, lr=1e-3, max_norm=1.0), fused_mlp.FusedMLP(net_b.layers, lr=1e-3, max_norm=1.0)
+    for _ in range(2):
+        la = ta.train_pass(0, x, actions, old_lp, adv, count, 0.2).clone()
+        ga = ta.grad.clone()
+        ta.step()
+        lb = tb.train_step(0, x, actions, old_lp, adv, count, 0.2).clone()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(tb.grad.cpu().numpy(), ga.cpu().numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(float(lb), float(la), rtol=1e-6)
+        assert float(tb.step_count) == float(ta.step_count)
+        np.testing.assert_allclose(tb.flat.cpu().numpy(), ta.flat.cpu().numpy(), rtol=1e-5, atol=1e-7)
