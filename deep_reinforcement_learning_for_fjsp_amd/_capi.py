@@ -70,6 +70,7 @@ SIGNATURES = {
     "fjsp_rollout_destroy": (None, [_vp]),
     "fjsp_rollout_append": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fjsp_rollout_returns": (C.c_int, [_vp, _dbl, _vp]),
+    "fjsp_rollout_returns_normalised": (C.c_int, [_vp, C.c_double, _i32, _i32, _vp, _vp]),
     "fjsp_rollout_clear": (C.c_int, [_vp]),
     "fjsp_rollout_len": (C.c_int, [_vp]),
     "fjsp_rollout_ptr": (_vp, [_vp, _i32]),

@@ -95,6 +95,15 @@ class RolloutBuffer(object):
         check(self._lib.fjsp_rollout_returns(self._h, float(gamma), self._stream()))
         return self.returns[:len(self)]
 
+    def normalised_returns(self, gamma, normalized=True, standardized=True):
+        """compute_returns() + the per-episode normalisation of MPPPO.py:258-261 in one launch."""
+        n = len(self)
+        if getattr(self, "_norm", None) is None or self._norm.shape != self.returns.shape:
+            self._norm = torch.zeros_like(self.returns)
+        check(self._lib.fjsp_rollout_returns_normalised(self._h, float(gamma), 1 if normalized else 0, 1 if standardized else 0,
+                                                        C.c_void_p(self._norm.data_ptr()), self._stream()))
+        return self._norm[:n]
+
     def sample(self):
         n = len(self)
         return self.states[:n], self.actions[:n], self.rewards[:n], self.next_states[:n], self.dones[:n]

@@ -299,8 +299,8 @@ class PPOLearner(object):
 
     def equalise_policies(self):
         """:372-375 with the AttributeError fixed."""
-        for old_param, new_param in zip(self.actor_old.parameters(), self.actor_new.parameters()):
-            old_param.data.copy_(new_param.data)
+        with torch.no_grad():
+            torch._foreach_copy_([p.data for p in self.actor_old.parameters()], [p.data for p in self.actor_new.parameters()])
 
 
 class FusedSampler(object):
@@ -513,8 +513,11 @@ def collect_and_learn(env, learner, memory_holder, exploration, max_steps, encod
     if fused is not None:
         actions = fused.flat_actions[:n].unsqueeze(-1)
     valid = memory.valid[:n]
-    G = memory.compute_returns(hp["discount_rate"])
-    G = normalise_returns(G, valid, hp["normalized_rewards"], hp["standardized_rewards"])
+    if hasattr(memory, "normalised_returns"):        # device rollout buffer: scan + normalisation in one launch
+        G = memory.normalised_returns(hp["discount_rate"], hp["normalized_rewards"], hp["standardized_rewards"])
+    else:
+        G = memory.compute_returns(hp["discount_rate"])
+        G = normalise_returns(G, valid, hp["normalized_rewards"], hp["standardized_rewards"])
     losses = learner.learn(states, actions[..., 0].long(), old_log_prob[:n], G, valid)
     return memory, losses
 

@@ -259,6 +259,10 @@ int fjsp_rollout_append(fjsp_rollout *b, const double *d_state, const uint8_t *d
 /* calculate_discounted_returns (agents/MPPPO/MPPPO.py:301-312): reverse scan
  * G_t = r_t + gamma * G_{t+1} per env over valid rows, f64 scan -> f32. */
 int fjsp_rollout_returns(fjsp_rollout *b, double gamma, void *stream);
+/* The same scan followed by the per-episode normalisation of MPPPO.py:258-261 (normalized: (G - min) / (max - min +
+ * 1e-8) over the env's valid rows; standardized: (G - mean) / (unbiased std + 1e-8)) in one launch; d_out
+ * f32[len][N] receives the result (0 in rows that are not valid), the buffer's returns the raw scan. */
+int fjsp_rollout_returns_normalised(fjsp_rollout *b, double gamma, int32_t normalized, int32_t standardized, float *d_out, void *stream);
 /* clear(): Buffer.py:53-55 */
 int fjsp_rollout_clear(fjsp_rollout *b);
 int fjsp_rollout_len(const fjsp_rollout *b);

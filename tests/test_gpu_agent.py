@@ -41,6 +41,13 @@ def test_rollout_buffer_append_and_returns(torch_gpu):
     got = buf.compute_returns(0.99)
     want = discounted_returns(rewards.cpu(), buf.valid[:n].cpu(), 0.99)
     assert torch.equal(got.cpu(), want)
+    # scan + per-episode normalisation (MPPPO.py:258-261) in one launch == the tensor-op version on the same returns
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import normalise_returns
+    for normalized, standardized in ((True, True), (True, False), (False, True), (False, False)):
+        gn = buf.normalised_returns(0.99, normalized, standardized)
+        wn = normalise_returns(want, buf.valid[:n].cpu(), normalized, standardized)
+        assert torch.equal(buf.returns[:n].cpu(), want)                              # the raw scan is still there
+        np.testing.assert_allclose(gn.cpu().numpy(), wn.numpy(), rtol=2e-5, atol=2e-6, err_msg="normalized=%s standardized=%s" % (normalized, standardized))
     buf.clear()
     assert len(buf) == 0
     for _ in range(T):
