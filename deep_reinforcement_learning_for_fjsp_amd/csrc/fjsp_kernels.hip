@@ -60,6 +60,12 @@ template <int V>
 constexpr bool is_so_v = (V == FJSP_VARIANT_SO_FJSSP || V == kMord);
 template <int V>
 constexpr bool is_mord_v = (V == kMord || V == kDyn);
+// observation sizes per variant (the host's DevBatch.n_obs / n_static / state_size, fjsp_env.hip): compile-time here, so
+// the kernels do not fetch them from the kernel arguments
+template <int V>
+constexpr int kNObs = is_so_v<V> ? 10 : (V == kDyn ? 15 : 9);
+template <int V>
+constexpr int kNStatic = V == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 7 : 0;
 #ifndef FJSP_SHARED_TAIL
 #define FJSP_SHARED_TAIL 1
 #endif
@@ -309,15 +315,16 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int JP, int MP, int KP, boo
 template <int KC, int V, int SJ = -1>
 __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env, unsigned char *lds, bool un_lds,
                                          bool load_state, bool want_stats = false) {
-    w.KP = b->KP; w.MP = b->MP; w.JP = b->JP; w.n_obs = b->n_obs; w.n_static = b->n_static;
-    w.state_size = b->state_size;
+    w.KP = kWave * KC;       // (KP = 64 KC by construction, fjsp_env.hip)
+    w.MP = b->MP; w.JP = b->JP; w.n_obs = kNObs<V>; w.n_static = kNStatic<V>;
+    w.state_size = kNStatic<V> + 2 * kNObs<V>;
     w.single_job = SJ < 0 ? (!is_mord_v<V> && b->single_job != 0) : (SJ != 0);
     w.jreg = SJ == 1 && KC == 1;
     w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats; w.e_asg = b->L.e_asg;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = b->n_inst == b->N ? env : env % b->n_inst;     // (one instance per environment: no division)
-    const int JP = b->JP, KP = b->KP, MP = b->MP;
+    const int JP = b->JP, KP = kWave * KC, MP = b->MP;
     const Layout &L = b->L;
     const unsigned char *ir = b->inst + (size_t)w.inst * L.i_stride;
     unsigned char *er = b->envs + (size_t)env * L.e_stride;
@@ -1667,7 +1674,7 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
     } else {
         a0 = uni((int)actions[(size_t)env * 2]); a1 = uni((int)actions[(size_t)env * 2 + 1]);
     }
-    const uint32_t lds_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, b.KP, false);
+    const uint32_t lds_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, kWave * KC, false);
     open_env<KC, V, SJ ? 1 : 0>(w, &b, env, fjsp_lds + wave * lds_stride, false, true, true);
     if (env_raw >= b.N) return;                       // (a finished wave no longer counts at the workgroup's barriers)
     STAMP(w, 0);
@@ -1750,13 +1757,13 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
             if (!go && w.lane == 0) w.hdrL[H_N8] = 0;
             tail_sync<true>();
             STAMP(w, 7);
-            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, b.KP, false);
+            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, kWave * KC, false);
             tail_sync<true>();
             STAMP(w, 8);
             if (go) observe_deviations<KC, V>(w, frv, grv);
             tail_sync<true>();
             STAMP(w, 9);
-            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, b.KP, true);
+            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, kWave * KC, true);
             tail_sync<true>();
             STAMP(w, 10);
             if (go) {
