@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 out = os.path.join(REPO, ".diag", "libfjsp_amd_stamps.so")
 csrc = os.path.join(REPO, "deep_reinforcement_learning_for_fjsp_amd", "csrc")
-srcs = [os.path.join(csrc, f) for f in ("fjsp_kernels.hip", "fjsp_env.hip", "fjsp_rollout_buffer.hip",
+srcs = [os.path.join(csrc, f) for f in ("fjsp_kernels.hip", "fjsp_env.hip", "fjsp_rollout_buffer.hip", "fjsp_ppo.hip", "fjsp_mlp_train.hip",
                                          "fjsp_instance.cpp", "fjsp_lp.cpp")]
 os.makedirs(os.path.dirname(out), exist_ok=True)
 if not (os.path.exists(out) and "--no-build" in sys.argv):
