@@ -856,6 +856,7 @@ int fjsp_env_step_async(fjsp_env *e, const uint8_t *d_actions, const double *d_m
                         uint8_t *d_done, uint8_t *d_ready, void *stream) {
     if (!e || !d_actions || !d_ready) { set_error("fjsp_env_step_async: null argument"); return FJSP_E_ARG; }
     if (e->failed) { set_error("fjsp_env_step_async: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
+    if (reinterpret_cast<uintptr_t>(d_actions) & 1) { set_error("fjsp_env_step_async: d_actions must be 2-byte aligned"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
     hipStream_t st = (hipStream_t)stream;
     if (!e->b.mord) {                               // nothing ever parks: the plain step, every env ready
@@ -923,6 +924,7 @@ int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_
     if (!e || !d_actions) { set_error("fjsp_env_step: null argument"); return FJSP_E_ARG; }
     if (e->failed) { set_error("fjsp_env_step: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
     if (!async_idle(e)) { set_error("fjsp_env_step: environments are parked in the asynchronous arrival service; call fjsp_env_arrivals_flush first"); return FJSP_E_STATE; }
+    if (reinterpret_cast<uintptr_t>(d_actions) & 1) { set_error("fjsp_env_step_traced: d_actions must be 2-byte aligned"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
     if (launch_step(e->b, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, d_trace_km, (hipStream_t)stream) != 0) {
         set_error("step_kernel launch failed"); return FJSP_E_HIP;
@@ -941,6 +943,7 @@ int fjsp_env_rollout(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, 
     if (!e || !d_actions || T <= 0) { set_error("fjsp_env_rollout: bad arguments"); return FJSP_E_ARG; }
     if (e->failed) { set_error("fjsp_env_rollout: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
     if (!async_idle(e)) { set_error("fjsp_env_rollout: environments are parked in the asynchronous arrival service; call fjsp_env_arrivals_flush first"); return FJSP_E_STATE; }
+    if (reinterpret_cast<uintptr_t>(d_actions) & 1) { set_error("fjsp_env_rollout: d_actions must be 2-byte aligned"); return FJSP_E_ARG; }
     DeviceGuard guard(e->device);
     hipStream_t st = (hipStream_t)stream;
     if (!e->b.mord && rollout_lds_bytes(e->b) <= 64 * 1024) {

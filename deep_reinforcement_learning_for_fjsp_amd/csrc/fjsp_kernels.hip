@@ -1665,18 +1665,15 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
 #endif
     W<KC, V> w;
     STAMP_BEGIN(w);
-    // the action pair is wave-uniform: one scalar load when the tensor is 4-byte aligned (it is, unless a caller
-    // slices an odd number of environments off a larger tensor)
-    int a0, a1;
-    if ((reinterpret_cast<uintptr_t>(actions) & 3u) == 0) {
-        const uint32_t word = reinterpret_cast<const uint32_t *>(actions)[env >> 1] >> ((env & 1) * 16);
-        a0 = (int)(word & 0xFFu); a1 = (int)((word >> 8) & 0xFFu);
-    } else {
-        a0 = uni((int)actions[(size_t)env * 2]); a1 = uni((int)actions[(size_t)env * 2 + 1]);
-    }
+    // The action pair (wave-uniform, 2-byte aligned: checked by the host entry points) comes through the VECTOR memory
+    // path and is only moved to scalar registers after the state loads are out: a scalar load of it here would be waited
+    // for at once -- scalar loads return out of order, every wait on one drains them all -- one full memory round trip
+    // before the first state load could be issued.
+    const uint32_t araw = reinterpret_cast<const uint16_t *>(actions)[env];
     const uint32_t lds_stride = (uint32_t)lds_bytes_per_wave(b.JP, b.MP, kWave * KC, false);
     open_env<KC, V, SJ ? 1 : 0>(w, &b, env, fjsp_lds + wave * lds_stride, false, true, true);
     if (env_raw >= b.N) return;                       // (a finished wave no longer counts at the workgroup's barriers)
+    const int a0 = uni((int)(araw & 0xFFu)), a1 = uni((int)(araw >> 8));
     STAMP(w, 0);
 #if defined(FJSP_ABLATE) && FJSP_ABLATE == 4
     store_dynamic<KC, V>(w, false);                // diagnostic: state in / state out only
