@@ -162,6 +162,8 @@ class EnvBatch(object):
         if not (torch.is_tensor(actions) and actions.dtype is torch.uint8 and actions.shape == self._act_shape
                 and actions.device == self.device and actions.is_contiguous()):
             actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
+        if actions.data_ptr() & 1:                # the kernels read an action pair as one 16-bit word
+            actions = actions.clone()
         p_mo = None
         if mo is not None:
             mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
@@ -197,6 +199,8 @@ class EnvBatch(object):
         ready[i] = 1 where this call completed a step of env i; a parked env ignored its action -- present it again.
         Call flush_arrivals() before read() / reset() / step() / rollout()."""
         actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
+        if actions.data_ptr() & 1:
+            actions = actions.clone()
         mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
         if getattr(self, "ready", None) is None:
             self.ready = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
@@ -230,6 +234,8 @@ class EnvBatch(object):
         if actions.dim() != 3:
             raise ValueError("actions must have shape (T, %d, 2), got %s" % (self.N, tuple(actions.shape)))
         actions = _as_input("actions", actions, (actions.shape[0], self.N, 2), torch.uint8, self.device)
+        if actions.data_ptr() & 1:
+            actions = actions.clone()
         mo = _as_input("mo", mo, (self.N, 4), torch.float64, self.device)
         T = actions.shape[0]
         tr = torch.full((T, self.N, 2), -1, dtype=torch.int16, device=self.device) if trace else None

@@ -176,7 +176,7 @@ int fjsp_env_reset(fjsp_env *e, const uint8_t *d_mask, double *d_state, void *st
  * rebuilds it first, so states stay identical to the reference's whatever the
  * mix of calls.  Envs already done are left untouched and get
  * FJSP_ST_STEP_AFTER_DONE unless autoreset != 0, in which case a done env is
- * reset first and the step applies to the fresh episode. */
+ * reset first and the step applies to the fresh episode.  * d_actions must be 2-byte aligned (the kernels read an env's pair as one 16-bit word): FJSP_E_ARG otherwise. */
 int fjsp_env_step(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset,
                   double *d_state, double *d_reward, uint8_t *d_done, void *stream);
 /* The same step, also reporting what the rule pair resolved to: d_trace_km

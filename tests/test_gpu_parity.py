@@ -767,6 +767,19 @@ def test_wrong_tensor_arguments_are_rejected_before_any_launch(torch_gpu):
     # inputs of another dtype / on the host are converted, as before
     b.step(torch.zeros(N, 2, dtype=torch.int64), mo=torch.tensor([[0.0, 1.0, 0.0, 0.0]] * N, dtype=torch.float32))
     assert int((b.read()["status"] != 0).sum()) == 0
+    # an action tensor at an odd address (the kernels read a pair as one 16-bit word): the C ABI refuses it, EnvBatch
+    # re-homes it and the step is the one the aligned tensor gives
+    from deep_reinforcement_learning_for_fjsp_amd import _capi
+    odd = torch.zeros(2 * N + 1, dtype=torch.uint8, device=b.device)[1:].view(N, 2)
+    assert odd.data_ptr() & 1 and odd.is_contiguous()
+    rc = b._lib.fjsp_env_step(b._h, _capi.C.c_void_p(odd.data_ptr()), None, 0, None, None, None, None)
+    assert rc == -1 and b"2-byte aligned" in b._lib.fjsp_last_error()
+    odd[:] = 1
+    c = EnvBatch(fi.InstanceSet(N).generate_range(1, fi.bench_10x5_params()).solve_fluid(), N, variant=2)
+    c.reset(); b.reset()
+    s1, r1, _ = b.step(odd, mo=torch.tensor([[0.0, 1.0, 0.0, 0.0]] * N, dtype=torch.float64))
+    s2, r2, _ = c.step(torch.ones(N, 2, dtype=torch.uint8, device=b.device), mo=torch.tensor([[0.0, 1.0, 0.0, 0.0]] * N, dtype=torch.float64))
+    assert torch.equal(s1, s2) and torch.equal(r1, r2)
 
 
 def test_async_arrival_service_keeps_every_env_on_its_own_trajectory(torch_gpu):
