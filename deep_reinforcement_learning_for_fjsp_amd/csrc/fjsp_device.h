@@ -107,6 +107,29 @@ struct Layout {
     uint32_t e_lpq;     // u16[2][KP] LP inputs of the pending arrival: Q[k], n_now[k]; then i16[2] stashed (k, m) of the step
 };
 
+// Offsets that follow from the padded sizes alone (the host's layout code in fjsp_env.hip places these fields first,
+// in this order, and fjsp_env_create verifies the two agree): the kernels take them from here -- compile-time for the
+// per-k rows, two shifts for the head of the env record -- instead of fetching them from the kernel arguments, and the
+// constants fold into the loads' immediate offsets.
+struct FixedOffsets {
+    static constexpr uint32_t kInstHeader = 64, kEnvScalars = 192;
+    static constexpr __host__ __device__ uint32_t i_kA(uint32_t KP) { (void)KP; return kInstHeader; }
+    static constexpr __host__ __device__ uint32_t i_kB(uint32_t KP) { return kInstHeader + 4 * KP; }
+    static constexpr __host__ __device__ uint32_t i_elig(uint32_t KP) { return kInstHeader + 8 * KP; }
+    static constexpr __host__ __device__ uint32_t i_fmask(uint32_t KP) { return kInstHeader + 12 * KP; }
+    static constexpr __host__ __device__ uint32_t i_f4(uint32_t KP) { return kInstHeader + 16 * KP; }
+    static constexpr __host__ __device__ uint32_t i_rsum(uint32_t KP) { return kInstHeader + 20 * KP; }
+    static constexpr __host__ __device__ uint32_t i_tsum(uint32_t KP) { return kInstHeader + 28 * KP; }
+    static constexpr __host__ __device__ uint32_t i_due(uint32_t KP) { return kInstHeader + 36 * KP; }
+    static constexpr __host__ __device__ uint32_t e_tend() { return kEnvScalars; }
+    static constexpr __host__ __device__ uint32_t e_mjob(uint32_t MP) { return kEnvScalars + 4 * MP; }
+    static constexpr __host__ __device__ uint32_t e_jst(uint32_t MP) { return kEnvScalars + 8 * MP; }
+    static constexpr __host__ __device__ uint32_t e_un(uint32_t MP, uint32_t JP) { return kEnvScalars + 8 * MP + 4 * JP; }   // JP is a multiple of 64
+    static constexpr __host__ __device__ uint32_t e_asg(uint32_t MP, uint32_t JP, uint32_t KP, bool single_job) {
+        return e_un(MP, JP) + (single_job ? 8u : 8u * MP * KP);
+    }
+};
+
 struct DevBatch {
     int32_t N, n_inst, KC, KP, MP, JP, variant, n_obs, n_static, state_size;
     int32_t mord, SP, RP;    // multi-order batch (S > 1): order / kind paddings of i_oarr, i_ocnt

@@ -397,6 +397,15 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         L.e_stats = b.single_job ? 0u : take(KP * 64, 64);
         L.e_stride = (uint32_t)((o + 255) / 256 * 256);
     }
+    {   // the kernels compute these offsets themselves (FixedOffsets, fjsp_device.h): the two must agree
+        using F = FixedOffsets;
+        const uint32_t kp = (uint32_t)KP, mp = (uint32_t)MP, jp = (uint32_t)JP;
+        const bool same = L.i_kA == F::i_kA(kp) && L.i_kB == F::i_kB(kp) && L.i_elig == F::i_elig(kp) && L.i_fmask == F::i_fmask(kp) &&
+                          L.i_f4 == F::i_f4(kp) && L.i_rsum == F::i_rsum(kp) && L.i_tsum == F::i_tsum(kp) && L.i_due == F::i_due(kp) &&
+                          L.e_tend == F::e_tend() && L.e_mjob == F::e_mjob(mp) && L.e_jst == F::e_jst(mp) && L.e_un == F::e_un(mp, jp) &&
+                          L.e_asg == F::e_asg(mp, jp, kp, b.single_job != 0);
+        if (!same) { delete e; set_error("fjsp_env_create: record layout and FixedOffsets disagree (internal error)"); return FJSP_E_UNSUPPORTED; }
+    }
     std::vector<unsigned char> islab(NI * L.i_stride, 0);
     auto ip = [&](size_t i, uint32_t off) { return islab.data() + i * L.i_stride + off; };
     double bytes_acc = 0.0;

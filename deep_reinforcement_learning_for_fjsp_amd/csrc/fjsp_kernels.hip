@@ -320,7 +320,13 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.state_size = kNStatic<V> + 2 * kNObs<V>;
     w.single_job = SJ < 0 ? (!is_mord_v<V> && b->single_job != 0) : (SJ != 0);
     w.jreg = SJ == 1 && KC == 1;
-    w.e_jst = b->L.e_jst; w.e_tend = b->L.e_tend; w.e_mjob = b->L.e_mjob; w.e_un = b->L.e_un; w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats; w.e_asg = b->L.e_asg;
+    // (offsets that follow from the padded sizes: FixedOffsets, fjsp_device.h -- no kernel-argument fetch)
+    using FO = FixedOffsets;
+    constexpr uint32_t KPc = kWave * KC;
+    w.e_tend = FO::e_tend(); w.e_mjob = FO::e_mjob((uint32_t)b->MP); w.e_jst = FO::e_jst((uint32_t)b->MP);
+    w.e_un = FO::e_un((uint32_t)b->MP, (uint32_t)b->JP);
+    w.e_asg = FO::e_asg((uint32_t)b->MP, (uint32_t)b->JP, KPc, w.single_job);
+    w.e_dyn = b->L.e_dyn; w.e_stats = b->L.e_stats;
     w.env = env;
     w.lane = (int)__lane_id();
     w.inst = b->n_inst == b->N ? env : env % b->n_inst;     // (one instance per environment: no division)
@@ -335,7 +341,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.frL = w.scrL + 24; w.grL = w.frL + KP + 2; w.tdL = w.grL + KP + 2;
     unsigned char *q = reinterpret_cast<unsigned char *>(w.tdL + KP + 2);
     if (un_lds) { w.unp = reinterpret_cast<double *>(q); q += (size_t)MP * KP * 8; }
-    else w.unp = reinterpret_cast<double *>(er + L.e_un);
+    else w.unp = reinterpret_cast<double *>(er + w.e_un);
     w.jstL = reinterpret_cast<uint32_t *>(q); q += (size_t)JP * 4;
     w.dueL = reinterpret_cast<int32_t *>(q);
     // ---- issue every load
@@ -343,25 +349,25 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int k = c * kWave + w.lane;
-        w.kB[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kB)[k];
+        w.kB[c] = reinterpret_cast<const uint32_t *>(ir + FO::i_kB(KPc))[k];
         // one job per kind: first job = kind index, one job (nothing to fetch); padding lanes have no job
         w.kA[c] = 0;
-        if (!w.single_job) w.kA[c] = reinterpret_cast<const uint32_t *>(ir + L.i_kA)[k];
-        w.elig[c] = reinterpret_cast<const uint32_t *>(ir + L.i_elig)[k];
+        if (!w.single_job) w.kA[c] = reinterpret_cast<const uint32_t *>(ir + FO::i_kA(KPc))[k];
+        w.elig[c] = reinterpret_cast<const uint32_t *>(ir + FO::i_elig(KPc))[k];
         // the file order of the first four machines only matters to CPython's set order beyond 8 machines (fjsp_pyset.h)
         w.first4[c] = 0;
-        if (MP > 8) w.first4[c] = reinterpret_cast<const uint32_t *>(ir + L.i_f4)[k];
+        if (MP > 8) w.first4[c] = reinterpret_cast<const uint32_t *>(ir + FO::i_f4(KPc))[k];
         w.asg[c] = 0xFFu;
-        if (w.single_job && load_state) w.asg[c] = reinterpret_cast<const uint8_t *>(er + L.e_asg)[k];
+        if (w.single_job && load_state) w.asg[c] = reinterpret_cast<const uint8_t *>(er + w.e_asg)[k];
         if (is_mord_v<V> && load_state) {      // tables of the last LP of THIS environment
             w.fmask[c] = reinterpret_cast<const uint32_t *>(er + L.e_fmask)[k];
             w.rate_sum[c] = reinterpret_cast<const double *>(er + L.e_rsum)[k];
             w.time_sum[c] = reinterpret_cast<const double *>(er + L.e_tsum)[k];
             w.q0[c] = (int)reinterpret_cast<const uint32_t *>(er + L.e_q0)[k];
         } else {
-            w.fmask[c] = reinterpret_cast<const uint32_t *>(ir + L.i_fmask)[k];
-            w.rate_sum[c] = reinterpret_cast<const double *>(ir + L.i_rsum)[k];
-            w.time_sum[c] = reinterpret_cast<const double *>(ir + L.i_tsum)[k];
+            w.fmask[c] = reinterpret_cast<const uint32_t *>(ir + FO::i_fmask(KPc))[k];
+            w.rate_sum[c] = reinterpret_cast<const double *>(ir + FO::i_rsum(KPc))[k];
+            w.time_sum[c] = reinterpret_cast<const double *>(ir + FO::i_tsum(KPc))[k];
             w.q0[c] = 0;                     // = jobs of the kind, set below
         }
     }
@@ -378,7 +384,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     }
     const int jcap = b->jcap;
     int32_t due0 = 0;
-    if (w.lane < jcap) due0 = reinterpret_cast<const int32_t *>(ir + L.i_due)[w.lane];       // JP >= 64
+    if (w.lane < jcap) due0 = reinterpret_cast<const int32_t *>(ir + FO::i_due(KPc))[w.lane];       // JP >= 64
     uint32_t jst0 = 0;
     int tend0 = 0, mjob0 = -1, tlast0 = -1, ipw0 = 0;
     double obs0 = 0.0;
@@ -386,7 +392,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     if (V == kDyn && w.lane < MP) ipw0 = reinterpret_cast<const int32_t *>(ir + L.i_ipw)[w.lane];
     EnvScalars sc;      // uniform address: the compiler fetches it with scalar loads, no cross-lane traffic
     if (load_state) {
-        if (w.lane < jcap) jst0 = reinterpret_cast<const uint32_t *>(er + L.e_jst)[w.lane];
+        if (w.lane < jcap) jst0 = reinterpret_cast<const uint32_t *>(er + w.e_jst)[w.lane];
         const EnvScalars *es = reinterpret_cast<const EnvScalars *>(er);
         sc.t = es->t; sc.step_count = es->step_count; sc.done = es->done; sc.n_unassigned = es->n_unassigned;
         sc.status = es->status; sc.seq_ctr = es->seq_ctr; sc.rng_calls = es->rng_calls; sc.busy = es->busy;
@@ -395,8 +401,8 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         sc.t_arr = es->t_arr; sc.next_order = es->next_order; sc.pending = es->pending; sc.obs_stale = es->obs_stale;
         if (w.lane < 10) obs0 = es->obs_prev[w.lane];
         if (w.lane < MP) {
-            tend0 = reinterpret_cast<const int32_t *>(er + L.e_tend)[w.lane];
-            mjob0 = reinterpret_cast<const int32_t *>(er + L.e_mjob)[w.lane];
+            tend0 = reinterpret_cast<const int32_t *>(er + w.e_tend)[w.lane];
+            mjob0 = reinterpret_cast<const int32_t *>(er + w.e_mjob)[w.lane];
         }
         if (V == kDyn) {
             const DynScalars *ds = reinterpret_cast<const DynScalars *>(er + L.e_dyn);
@@ -434,12 +440,12 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
         }
     } else {
         w.dueL[w.lane] = due0;
-        for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + L.i_due)[n];
+        for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + FO::i_due(KPc))[n];
     }
     if (!load_state) return;
     if (!w.jreg) {
         w.jstL[w.lane] = jst0;
-        for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + L.e_jst)[n];
+        for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + w.e_jst)[n];
     }
     w.t = uni(sc.t); w.step_count = uni(sc.step_count); w.done = uni(sc.done); w.n_unassigned = uni(sc.n_unassigned);
     w.status = uniu(sc.status); w.seq_ctr = uniu(sc.seq_ctr); w.rng_calls = uniu(sc.rng_calls); w.busy = uniu(sc.busy);
@@ -453,7 +459,7 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     w.mjob_m = w.lane < w.M ? mjob0 : -1;
     if (V == kDyn) { w.tlast_m = w.lane < w.M ? tlast0 : -1; w.energy = en0; w.energy_last = enl0; }
     if (un_lds && !w.single_job) {
-        const double *src = reinterpret_cast<const double *>(er + L.e_un);
+        const double *src = reinterpret_cast<const double *>(er + w.e_un);
         for (int i = w.lane; i < w.K * MP; i += kWave) w.unp[i] = src[i];
     }
     if (load_stats) {
