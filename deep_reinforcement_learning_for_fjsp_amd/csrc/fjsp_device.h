@@ -128,6 +128,12 @@ struct FixedOffsets {
     static constexpr __host__ __device__ uint32_t e_asg(uint32_t MP, uint32_t JP, uint32_t KP, bool single_job) {
         return e_un(MP, JP) + (single_job ? 8u : 8u * MP * KP);
     }
+    // single-order, non-dynamic batches: the env record ends with the assigned-machine bytes (single-job) or the 64-byte
+    // aligned statistics rows behind them
+    static constexpr __host__ __device__ uint32_t e_stride_plain(uint32_t MP, uint32_t JP, uint32_t KP, bool single_job) {
+        const uint32_t end = single_job ? e_asg(MP, JP, KP, true) + KP : ((e_asg(MP, JP, KP, false) + KP + 63u) & ~63u) + 64u * KP;
+        return (end + 255u) & ~255u;
+    }
 };
 
 struct DevBatch {

@@ -403,7 +403,8 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         const bool same = L.i_kA == F::i_kA(kp) && L.i_kB == F::i_kB(kp) && L.i_elig == F::i_elig(kp) && L.i_fmask == F::i_fmask(kp) &&
                           L.i_f4 == F::i_f4(kp) && L.i_rsum == F::i_rsum(kp) && L.i_tsum == F::i_tsum(kp) && L.i_due == F::i_due(kp) &&
                           L.e_tend == F::e_tend() && L.e_mjob == F::e_mjob(mp) && L.e_jst == F::e_jst(mp) && L.e_un == F::e_un(mp, jp) &&
-                          L.e_asg == F::e_asg(mp, jp, kp, b.single_job != 0);
+                          L.e_asg == F::e_asg(mp, jp, kp, b.single_job != 0) &&
+                          (b.mord || dyn || L.e_stride == F::e_stride_plain(mp, jp, kp, b.single_job != 0));
         if (!same) { delete e; set_error("fjsp_env_create: record layout and FixedOffsets disagree (internal error)"); return FJSP_E_UNSUPPORTED; }
     }
     std::vector<unsigned char> islab(NI * L.i_stride, 0);

@@ -333,7 +333,8 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
     const int JP = b->JP, KP = kWave * KC, MP = b->MP;
     const Layout &L = b->L;
     const unsigned char *ir = b->inst + (size_t)w.inst * L.i_stride;
-    unsigned char *er = b->envs + (size_t)env * L.e_stride;
+    const uint32_t e_stride = is_mord_v<V> ? L.e_stride : FO::e_stride_plain((uint32_t)MP, (uint32_t)JP, KPc, w.single_job);
+    unsigned char *er = b->envs + (size_t)env * e_stride;
     w.er = er;
     // LDS carve: [obs 16][tail header 16 x i32][fr KP][gr KP][td KP][un (optional)][jst][due]
     w.scrL = reinterpret_cast<double *>(lds);
