@@ -1,0 +1,95 @@
+// Device-side pieces shared by the two kernel families of the batched environment: fjsp_kernels.hip (one wavefront
+// per environment: every variant and shape) and fjsp_group.hip (one 16-lane DPP row per environment: single-job
+// batches of at most 64 operation types and 8 machines, the 10x5 / Brandimarte workloads).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/fjsp_amd.h"
+#include "fjsp_device.h"
+
+namespace fjsp {
+
+// Internal variant id: SO_FJSSP whose instance has more than one order (order arrivals re-solve the fluid
+// LP mid-episode, SO_FJSSP.py:218-231).  Its fluid tables live in the env record and its step can stop at
+// an arrival and be finished by arrival_kernel once the host has solved the LP.
+constexpr int kMord = 3;
+// MO_DFJSP_breakdown.py: the multi-order skeleton plus breakdown windows, energy, 12 x 10 rules, 15 observations.
+constexpr int kDyn = FJSP_VARIANT_MO_DFJSP;
+template <int V>
+constexpr bool is_so_v = (V == FJSP_VARIANT_SO_FJSSP || V == kMord);
+template <int V>
+constexpr bool is_mord_v = (V == kMord || V == kDyn);
+// observation sizes per variant (the host's DevBatch.n_obs / n_static / state_size, fjsp_env.hip): compile-time here, so
+// the kernels do not fetch them from the kernel arguments
+template <int V>
+constexpr int kNObs = is_so_v<V> ? 10 : (V == kDyn ? 15 : 9);
+template <int V>
+constexpr int kNStatic = V == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 7 : 0;
+
+template <int V>
+struct ObsPos {
+    // finish_rate, gap_rate, time_end: where the mean and the std of each go in the observation vector
+    static constexpr bool so = is_so_v<V>, mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES, sf = V == FJSP_VARIANT_SO_SFJSP;
+    static constexpr int ave0 = so ? 2 : (mo ? 1 : (sf ? 2 : 5)), ave1 = so ? 4 : (mo ? 3 : (sf ? 5 : 7)), ave2 = 15;
+    static constexpr int sd0 = so ? 3 : (mo ? 2 : (sf ? 3 : 6)), sd1 = so ? 5 : (mo ? 4 : (sf ? 6 : 8)),
+                         sd2 = so ? 1 : (mo ? 0 : (sf ? 1 : 3));
+    static constexpr int ratio0 = so ? 6 : (mo ? 5 : 11);    // (delay_a, delay_e)/tasks, (job_a, job_e)/jobs; unused slots for SO_SFJSP
+};
+
+
+#define DPP(v, ctrl, ident) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), 0xF, 0xF, false)
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+
+// Strictly sequential float sum of n8 (a multiple of 8, >= 8) operands held in LDS, left to right like
+// the reference's sum() (SO_FJSSP.py:86-95): (((0 + x0) + x1) + ...).  The chain itself costs 8 cycles per
+// dependent v_add_f64; what made it 40-54 cycles per element (tools/ubench/lds_chain.hip) was the LDS pipe: a
+// wave-wide read occupies it for the full 64 lanes even when three of them carry useful data.  So: 16-byte
+// reads (ds_read_b128: two operands per lane at half the pipe time of ds_read2_b64), rows skewed by 16 bytes
+// so that the rows walked side by side sit in different banks, and a ring of 16-byte registers refilled
+// a ring's length ahead, so the adds never wait for the LDS.  Entries past the real length hold +0.0, which is an
+// exact identity here (the running sum starts at +0.0 and can never become -0.0); the ring reads up to 2 RING
+// entries past n8: rows are followed by at least 128 bytes of the same LDS slice.  `src` is 16-byte aligned.
+// The compiler's scheduler sinks the refills of such a ring behind all the adds of a turn (and then waits for
+// them), so the walker of step_kernel -- alone on its SIMD while it walks, nothing else hides the LDS for it --
+// uses the form below: the reads and the waits are volatile asm statements (they keep their order), each wait
+// carries the register it waits for as an in/out operand (so the adds that consume it cannot move above it),
+// and the register allocation stays the compiler's: eight 16-byte registers, each refilled 16 elements ahead
+// right after its two operands are consumed; s_waitcnt lgkmcnt(7) waits for exactly the oldest read.
+typedef double fjsp_d2 __attribute__((ext_vector_type(2)));
+#define FJSP_LDS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define FJSP_LDS_WAIT(reg, cnt) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(cnt))
+__device__ __forceinline__ double lds_chain_sum_ring8(const double *src, int n8) {
+    double acc = 0.0;
+    uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(src);      // the low half of a flat LDS address is the LDS offset
+    const int n = __builtin_amdgcn_readfirstlane(n8);
+    fjsp_d2 A0, A1, A2, A3, A4, A5, A6, A7;
+    FJSP_LDS_READ128(A0, a, 0); FJSP_LDS_READ128(A1, a, 16); FJSP_LDS_READ128(A2, a, 32); FJSP_LDS_READ128(A3, a, 48);
+    FJSP_LDS_READ128(A4, a, 64); FJSP_LDS_READ128(A5, a, 80); FJSP_LDS_READ128(A6, a, 96); FJSP_LDS_READ128(A7, a, 112);
+    int i = 0;
+#define FJSP_RING_STEP(R, off) FJSP_LDS_WAIT(R, 7); acc = acc + R.x; acc = acc + R.y; FJSP_LDS_READ128(R, a, off);
+    for (; i + 16 <= n; i += 16) {       // whole turns: every register is refilled (unconditionally) once consumed
+        FJSP_RING_STEP(A0, 128) FJSP_RING_STEP(A1, 144) FJSP_RING_STEP(A2, 160) FJSP_RING_STEP(A3, 176)
+        FJSP_RING_STEP(A4, 192) FJSP_RING_STEP(A5, 208) FJSP_RING_STEP(A6, 224) FJSP_RING_STEP(A7, 240)
+        a += 128;
+    }
+#undef FJSP_RING_STEP
+    // drain: the refills of the last turn are never consumed, but they must have landed before their registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
+    if (i < n) {                         // n is a multiple of 8: eight operands left, in the first half of the ring
+        acc = acc + A0.x; acc = acc + A0.y; acc = acc + A1.x; acc = acc + A1.y;
+        acc = acc + A2.x; acc = acc + A2.y; acc = acc + A3.x; acc = acc + A3.y;
+    }
+    return acc;
+}
+
+
+}  // namespace fjsp

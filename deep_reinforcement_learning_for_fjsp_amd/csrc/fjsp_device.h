@@ -28,6 +28,10 @@ constexpr uint32_t kNoSeq = 0xFFFFFFu;
 
 // jstate word per job: next unassigned stage (8 bit) | FIFO sequence (24 bit, kNoSeq = not waiting)
 __host__ __device__ inline uint32_t jst_pack(uint32_t seq, uint32_t next_j) { return (seq << 8) | next_j; }
+// Where operation type k's byte sits in Layout::e_asg: inside each block of 64 the bytes of k, k + 16, k + 32, k + 48 share
+// one 32-bit word, so a lane of the group kernels (fjsp_group.hip: lane l of a 16-lane row owns k = 16 s + l) fetches the
+// bytes of its four slots with one load
+__host__ __device__ inline uint32_t asg_pos(uint32_t k) { return (k & ~63u) | ((k & 15u) << 2) | ((k >> 4) & 3u); }
 
 // Dynamic per-environment scalars, 18 x 8-byte words (loaded by lanes 0..17).
 struct EnvScalars {
@@ -87,6 +91,10 @@ struct Layout {
     uint32_t i_ipw;     // i32[MP]  power_m_dict (idle power)
     uint32_t i_bkoff;   // u16[MP+1] first breakdown window of machine m in i_bk
     uint32_t i_bk;      // i32[BP][2] breakdown windows (start, end), machine-major, file order
+    // group-kernel batches only (DevBatch::grp): the static per-operation rows once more, packed for one 16-lane row per
+    // environment -- slot s (k = 16 s + l): 16 x uint4 {kB, elig | fmask << 8, due date of the kind's job, 0}, then
+    // 16 x double2 {fluid_rate_sum, fluid_time_sum}: two 16-byte loads per lane and slot  [written by fluid_tables_kernel]
+    uint32_t i_op;
     // env record: EnvScalars at 0
     uint32_t e_stride;
     uint32_t e_tend;    // i32[MP]  machine.time_end
@@ -142,6 +150,9 @@ struct DevBatch {
     int32_t single_job;      // every kind of every instance has one job and there is one order (10x5, the Brandimarte sets):
                              // per-(r, j) lists have at most one member, job index == kind index
     int32_t jcap;            // jobs of the largest instance, rounded up to 16: lanes beyond it load no job words
+    int32_t grp;             // 1 = the batch fits the group kernels (fjsp_group.hip): one job per kind, one order, <= 64 operation
+                             // types, <= 8 machines, <= 15 jobs, SO_FJSSP or MO_FJSSP_discretes
+    int32_t kmax;            // operation types of the largest instance
     uint32_t *pending_count; // [0] number of envs parked at an order arrival by the last launch, [1 + slot] their env ids
     uint16_t *lp_in;         // [slot][2][KP] LP inputs (Q, n_now) of the parked env in that slot (written when it parks)
     double *lp_x;            // [slot][KP][MP] fluid solution of that LP (uploaded by the host service, read by arrival_kernel)
@@ -166,6 +177,11 @@ int launch_reset(const DevBatch &b, const uint8_t *mask, double *state, hipStrea
 // ready (nullable, multi-order batches): asynchronous arrival service, see fjsp_env_step_async
 int launch_step(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                 uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready = nullptr);
+// the same step by the group kernels (fjsp_group.hip; DevBatch::grp batches only)
+int launch_step_group(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
+                      uint8_t *done, int16_t *trace_km, hipStream_t st);
+int launch_rollout_group(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
+                         double *state_last, hipStream_t st);
 size_t rollout_lds_bytes(const DevBatch &b);
 size_t step_lds_bytes(const DevBatch &b);     // dynamic LDS of one reset / step / arrival workgroup
 int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,

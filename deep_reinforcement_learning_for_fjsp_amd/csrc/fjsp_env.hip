@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <functional>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -360,6 +361,13 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.mord = (Smax > 1 || dyn) ? 1 : 0; b.SP = Smax; b.RP = Rmax;     // MO_DFJSP always runs on the per-env fluid tables
     b.single_job = (single_job && !b.mord) ? 1 : 0;
     b.jcap = std::min(b.JP, (Jmax + 15) / 16 * 16);
+    b.kmax = Kmax;
+    // one 16-lane row per environment (fjsp_group.hip): FJSP_STEP_IMPL=wave keeps such batches on the one-wave-per-environment kernels
+    {
+        const char *impl = getenv("FJSP_STEP_IMPL");
+        b.grp = (b.single_job && Kmax <= 64 && Mmax <= 8 && Jmax <= 15 &&
+                 (variant == FJSP_VARIANT_SO_FJSSP || variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) && !(impl && strcmp(impl, "wave") == 0)) ? 1 : 0;
+    }
     if (step_lds_bytes(b) > 160 * 1024) {
         // four environments per workgroup keep their job tables (8 bytes per job) in the CU's 160 KB of LDS
         char msg[200];
@@ -386,6 +394,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             L.i_pw = take(MP * KP * 2, 4); L.i_ipw = take(MP * 4, 4); L.i_bkoff = take((MP + 1) * 2, 4);
             L.i_bk = take((size_t)Bmax * 8, 8);
         }
+        L.i_op = b.grp ? take(2048, 256) : 0u;
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(b.single_job ? 8 : MP * KP * 8, 8); L.e_asg = take(KP, 4);
@@ -463,6 +472,15 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
                 first4[k] = f4;
             }
             jbeg += cnt;
+        }
+        if (b.grp) {
+            // group kernels (fjsp_group.hip): len(machine.kind_task_tuple), the divisor of Machine.gap_ave (class_FJSSP.py:144-146),
+            // in the spare word of the packed operation rows (slot 0, lane m)
+            for (int m = 0; m < in.M; ++m) {
+                uint32_t cnt = 0;
+                for (int k = 0; k < in.K; ++k) cnt += in.p[(size_t)k * in.M + m] > 0 ? 1u : 0u;
+                reinterpret_cast<uint32_t *>(ip(i, L.i_op))[4 * m + 3] = cnt;
+            }
         }
         if (dyn) {
             uint16_t *pw = reinterpret_cast<uint16_t *>(ip(i, L.i_pw));
