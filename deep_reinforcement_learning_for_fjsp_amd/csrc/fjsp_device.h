@@ -93,7 +93,8 @@ struct Layout {
     uint32_t i_bk;      // i32[BP][2] breakdown windows (start, end), machine-major, file order
     // group-kernel batches only (DevBatch::grp): the static per-operation rows once more, packed for one 16-lane row per
     // environment -- slot s (k = 16 s + l): 16 x uint4 {kB, elig | fmask << 8, due date of the kind's job, 0}, then
-    // 16 x double2 {fluid_rate_sum, fluid_time_sum}: two 16-byte loads per lane and slot  [written by fluid_tables_kernel]
+    // 16 x double2 {fluid_rate_sum, fluid_time_sum}: two 16-byte loads per lane and slot  [written by fluid_tables_kernel];
+    // behind the four slots one line of per-lane words (machine / job / instance: fjsp_env.hip) and the jobs' due dates
     uint32_t i_op;
     // env record: EnvScalars at 0
     uint32_t e_stride;

@@ -394,7 +394,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             L.i_pw = take(MP * KP * 2, 4); L.i_ipw = take(MP * 4, 4); L.i_bkoff = take((MP + 1) * 2, 4);
             L.i_bk = take((size_t)Bmax * 8, 8);
         }
-        L.i_op = b.grp ? take(2048, 256) : 0u;
+        L.i_op = b.grp ? take(2048 + 128, 256) : 0u;
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(b.single_job ? 8 : MP * KP * 8, 8); L.e_asg = take(KP, 4);
@@ -474,12 +474,18 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             jbeg += cnt;
         }
         if (b.grp) {
-            // group kernels (fjsp_group.hip): len(machine.kind_task_tuple), the divisor of Machine.gap_ave (class_FJSSP.py:144-146),
-            // in the spare word of the packed operation rows (slot 0, lane m)
-            for (int m = 0; m < in.M; ++m) {
-                uint32_t cnt = 0;
-                for (int k = 0; k < in.K; ++k) cnt += in.p[(size_t)k * in.M + m] > 0 ? 1u : 0u;
-                reinterpret_cast<uint32_t *>(ip(i, L.i_op))[4 * m + 3] = cnt;
+            // group kernels (fjsp_group.hip): one line of per-lane words behind the packed operation rows -- lane l:
+            // len(machine l .kind_task_tuple) (the divisor of Machine.gap_ave, class_FJSSP.py:144-146) | first operation type of
+            // job l << 8 | its J_r << 16 | (lanes 0, 1, 2: K, M, jobs) << 24; then the due date of job l (one job per kind: job = kind)
+            uint32_t *hw = reinterpret_cast<uint32_t *>(ip(i, L.i_op) + 2048);
+            int32_t *dj = reinterpret_cast<int32_t *>(ip(i, L.i_op) + 2048 + 64);
+            for (int l = 0; l < 16; ++l) {
+                uint32_t w = 0;
+                if (l < in.M)
+                    for (int k = 0; k < in.K; ++k) w += in.p[(size_t)k * in.M + l] > 0 ? 1u : 0u;
+                if (l < in.R) { w |= (uint32_t)in.koff[l] << 8; w |= (uint32_t)in.Jr[l] << 16; dj[l] = due[l]; }
+                w |= (uint32_t)(l == 0 ? in.K : (l == 1 ? in.M : (l == 2 ? nj : 0))) << 24;
+                hw[l] = w;
             }
         }
         if (dyn) {

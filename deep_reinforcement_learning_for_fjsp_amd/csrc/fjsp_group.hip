@@ -2,31 +2,41 @@
 // ONE 16-LANE DPP ROW PER ENVIRONMENT, four environments per wavefront.
 //
 // fjsp_kernels.hip gives every environment a whole wavefront; on the 10x5 / Brandimarte workloads (one job per kind,
-// K <= 64 operation types, M <= 8 machines) 40 of its 64 lanes carry an operation type, 5 a machine, and the
+// K <= 64 operation types, M <= 8 machines, <= 15 jobs) 40 of its 64 lanes carry an operation type, 5 a machine, and the
 // wave-uniform part of a step (the scalar stream, the reductions, the serial sums) is paid per environment.  Here
 //   * lane l of row g owns the operation types k = 16 s + l of environment g, s = 0..3 ("slots": registers);
-//   * lanes 0..M-1 of the row double as its machine lanes, lanes 0..njobs-1 as its job lanes (state word of job l),
-//     lane (8 + i) & 15 keeps observation i;
+//   * lanes 0..njobs-1 of the row double as its JOB lanes (state word of job l and the data of the job's CURRENT
+//     operation type), lanes 0..M-1 as its machine lanes, lane (8 + i) & 15 keeps observation i;
+//   * with one job per kind only the current operation of a waiting job can be available, and kind_task_tuple order
+//     among those is job order: task_select, the event loop's "is anything available" and update_parameter's per-job
+//     statistics run on the job lanes (one register per row instead of one per operation type); only the estimated-
+//     delay counts, the observation's operand rows and Machine.gap_ave walk the operation slots;
 //   * what was wave-uniform becomes row-uniform and lives in VGPRs: a value is read from a row's lane n with one DPP
 //     move (row_newbcast:n), from a computed lane with ds_bpermute_b32; reductions are four DPP steps inside the row
-//     (quad_perm, quad_perm, row_half_mirror, row_mirror) and leave the result in every lane of the row;
+//     (quad_perm, quad_perm, row_half_mirror, row_mirror) and leave the result in every lane of the row; a "first
+//     extremum wins" choice is a row maximum of an order-preserving 64-bit key and the first set bit of the row's 16
+//     bits of ballot(member && key == maximum);
 //   * control flow is wave-uniform only ("does any row of this wave need ...", a ballot): inside, lanes are predicated;
 //   * the strictly sequential f64 sums of the observation and of Machine.gap_ave are walked out of LDS rows by one
 //     lane per sum, all rows of the wave side by side (the chains of four environments cost one instruction stream);
-//   * the static per-operation data come from a packed copy of the instance rows (Layout::i_op: two 16-byte loads
-//     per slot), the assigned-machine bytes of a lane's four slots share one word (asg_pos()).
+//   * the static data come from a packed copy of the instance rows (Layout::i_op: two 16-byte loads per slot and one
+//     line of per-job / per-machine words), the assigned-machine bytes of a lane's four slots share one word (asg_pos());
+//     the (operation x machine) rows Machine.gap_ave needs are requested together with the state when the row's rule
+//     asks for them (they depend on nothing the step computes).
 // The records in HBM are the ones of fjsp_kernels.hip: reset, the fused policy rollout, read-back and every other
 // entry point keep working on the same batch, and a batch can be stepped by either family (FJSP_STEP_IMPL=wave).
 //
 // Reference restated (paths relative to the reference root), single-job form (every per-(r, j) list has at most one
 // member, job index == kind index):
-//   environments/SO_FJSSP.py:99-166   update_parameter -> g_params
+//   environments/SO_FJSSP.py:99-166   update_parameter -> g_task_select (keys), g_observe (statistics)
 //   environments/SO_FJSSP.py:168-250  step, first half -> g_task_select, g_machine_select, g_dispatch_advance
 //   environments/SO_FJSSP.py:267-322  task_select, machine_select (class_FJSSP.py:137-146 gap, gap_ave)
 //   environments/SO_FJSSP.py:78-97, 252-265 state_extract, reward -> g_observe, g_reward
 //   environments/MO_FJSSP_discretes.py:26,88-244 flat action, three machine rules, weighted reward
 // Compiled with -ffp-contract=off: a*b+c must round twice like CPython.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "../../include/fjsp_amd.h"
 #include "fjsp_common.h"
@@ -38,19 +48,24 @@ namespace fjsp {
 namespace grp {
 
 constexpr int GS = 4;       // operation-type slots per lane
-constexpr int kNone = 255;  // "no lane" in a first-hit reduction
+constexpr int KS = 66;      // doubles per LDS row: 16 GS + 2 (16-byte aligned rows; (2 KS) mod 64 = 4: the rows that are walked
+                            // side by side start in different banks)
+constexpr uint32_t kSeqNone = kNoSeq << 8;      // state words at or above it: the job is not waiting
 
 #define GDEV __device__ __forceinline__
+// slots 0..2 are always processed (an instance of at most 32 operation types wastes slot 2: rare shapes), slot 3 -- operation
+// types 48..63 -- only when some row of the wave has that many: one wave-uniform branch per section instead of four
+#define SLOT_ON(e, s) ((s) < 3 || (e).nslots > 3)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
 // ---- row primitives
 template <int N>
-GDEV int bc(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, false); }       // row_newbcast:N
+GDEV int bc(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, false); }       // row_newbcast:N (every lane is read from: `old` is never used)
 template <int N>
 GDEV uint32_t bcu(uint32_t v) { return (uint32_t)bc<N>((int)v); }
 template <int N>
-GDEV long long bcl(long long v) { return __builtin_amdgcn_update_dpp(0ll, v, 0x150 + N, 0xF, 0xF, false); }
+GDEV long long bcl(long long v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, false); }
 template <int N>
 GDEV double bcd(double v) { return __longlong_as_double(bcl<N>(__double_as_longlong(v))); }
 // the value lane `idx` (0..15, any per-lane value) of the caller's row holds
@@ -80,33 +95,41 @@ GDEV void lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
+// a[s] for a per-lane slot index, written as selects between VALUES (an indexed load would pin the row state in scratch)
+// (the values pass through an empty asm statement: a select between loads would be rewritten into a load through a selected
+// ADDRESS)
+GDEV uint32_t pick_slot(const uint32_t (&a)[GS], int s) {
+    uint32_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    const uint32_t lo = (s & 1) ? a1 : a0, hi = (s & 1) ? a3 : a2;
+    return (s & 2) ? hi : lo;
+}
 
 // order-preserving 64-bit image of an f64 key (-0.0 folded onto +0.0: they compare equal in Python); keys are finite
 GDEV uint64_t sortable(double z0) {
     const double z = z0 + 0.0;
-    const uint32_t zh = (uint32_t)__double2hiint(z), zl = (uint32_t)__double2loint(z);
-    const bool neg = (zh >> 31) != 0;
-    return ((uint64_t)(neg ? ~zh : (zh | 0x80000000u)) << 32) | (uint64_t)(neg ? ~zl : zl);
+    uint32_t hi = (uint32_t)__double2hiint(z), lo = (uint32_t)__double2loint(z);
+    const uint32_t sg = (uint32_t)((int)hi >> 31);
+    hi ^= sg | 0x80000000u; lo ^= sg;
+    return ((uint64_t)hi << 32) | lo;
 }
 GDEV uint64_t sortable_max_i32(int v) { return (uint64_t)((uint32_t)v ^ 0x80000000u) << 32; }
 GDEV uint64_t sortable_min_i32(int v) { return (uint64_t)(~((uint32_t)v ^ 0x80000000u)) << 32; }
-// row maximum of a 64-bit unsigned key: high words, then the low words among the lanes that tie on the high word
-GDEV uint64_t gmax64(uint64_t v) {
-    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+// first member (lowest lane) of the row that attains the row maximum of `key`; 255 when the row has no member
+GDEV int first_max(bool mem, uint64_t key, int gb) {
+    const uint32_t hi = mem ? (uint32_t)(key >> 32) : 0u, lo = mem ? (uint32_t)key : 0u;
     const uint32_t mhi = gmaxu(hi);
-    const uint32_t mlo = gmaxu(hi == mhi ? lo : 0u);
-    return ((uint64_t)mhi << 32) | mlo;
+    const uint32_t mlo = gmaxu(hi == mhi ? lo : 0u);      // the low words among the lanes that tie on the high word
+    const uint32_t hits = gballot(mem && hi == mhi && lo == mlo, gb);
+    return hits ? (int)__builtin_ctz(hits) : 255;
 }
 
-// per-row LDS: RW rows of KS doubles (operands of the serial sums); KS = n8(kmax) + 2 keeps rows 16-byte aligned and the
-// rows that are walked side by side in different banks ((2 KS) mod 64 is an odd multiple of 4 for every n8)
-GDEV int row_stride(int kmax) { return ((kmax + 7) & ~7) + 2; }
-__host__ __device__ inline size_t group_lds_bytes(int kmax, int MP) {
-    const int ks = ((kmax + 7) & ~7) + 2, rw = MP < 2 ? 2 : MP;
-    return (size_t)4 * rw * ks * 8 + 256;           // + the ring's read-ahead past the last row
-}
+template <int MPC>
+__host__ __device__ constexpr size_t group_lds_bytes() { return (size_t)4 * MPC * KS * 8 + 256; }   // + the ring's read-ahead
 
 // ------------------------------------------------------------------ row state
+struct MoW { double w0, w1, cn, tn; };      // MO_FJSSP_discretes.py:88 weight vector + normalisers (defaults: d_mo == NULL)
+
 template <int V>
 struct GE {
     int l, gb, env;
@@ -114,17 +137,21 @@ struct GE {
     const unsigned char *ir;
     unsigned char *er;
     int MP;
-    int nslots;                // wave-uniform: slots any row of this wave uses
+    int nslots;                // wave-uniform: slots any row of this wave uses (the code tests slot 3 only: SLOT_ON)
     int n8w;                   // wave-uniform: operation types of the wave's largest instance, rounded up to 8 (length of a walk)
-    // lane = operation types 16 s + l
+    // lane = operation types 16 s + l.  Slots without an operation type carry kind 15 (no job lane: its word reads
+    // 0xFFFFFFFF = "stage 255"): never unassigned, and their fluid numbers are all 0
     uint32_t kB[GS], em[GS];   // stage | J_r << 8 | kind << 16 | flags << 24;  elig | fmask << 8
     int due[GS];
     double rsum[GS], tsum[GS];
-    uint32_t jw[GS];           // state word of the job of this slot's kind (copy of the job lane's)
     uint32_t asgw;             // byte s: machine operation type 16 s + l was assigned to (0xFF: not yet)
-    // lane = job / machine / observation
-    uint32_t jwl;
-    int tend, mjob, mcnt;      // mcnt: operation types machine l can process (static)
+    // lane = job: its state word (0xFFFFFFFF beyond njobs), first operation type | J_r << 8, due date, and of the
+    // job's current operation type (first + next stage): elig | fmask << 8, fluid_time_sum, fluid_rate_sum
+    uint32_t jwl, jinfo, emc;
+    int duej;
+    double tsumc, rsumc;
+    // lane = machine
+    int tend, mjob, mcnt;      // mcnt: operation types the machine can process (static)
     double obs_prev;           // lane (8 + i) & 15: observation i of the previous step
     // row-uniform
     int K, M, njobs;
@@ -135,44 +162,41 @@ struct GE {
     long long tard_done, delay_sum;
     uint64_t env_seed;
     double *rows;              // this row's LDS rows
-    int ks;
 };
 
-// per-slot results of update_parameter at the current clock (one job per kind: lists of at most one)
-struct GP {
-    bool in[GS], wait[GS], late[GS], cnte[GS];
-    double de[GS];             // estimated delay of the kind's job at this stage (:136-139) = max_e = sum_e = urgency
-    int da[GS];                // its actual delay t - due (:138) = max_a
-};
+// the (operation x machine) rows {arrival, rate} of a lane's slots, in flight while the step decides (g_cols_issue)
+template <int MPC>
+struct GCols { double2 c[GS][MPC]; };
 
+// the current operation type of every job lane: k = first + next stage, and its static data out of the operation slots
 template <int V>
-GDEV void g_refresh_jw(GE<V> &e) {
-#pragma unroll
-    for (int s = 0; s < GS; ++s)
-        if (s < e.nslots) e.jw[s] = greadu(e.jwl, (int)((e.kB[s] >> 16) & 0xFu), e.gb);
-}
-
-// SO_FJSSP.py:126-154 for lists of one (compute_params of fjsp_kernels.hip, single-job branch)
-template <int V>
-GDEV void g_params(const GE<V> &e, GP &p) {
-    const double td = (double)e.t;
+GDEV void g_gather_current(GE<V> &e, bool want_rsum) {
+    const int kc = (int)(e.jinfo & 0xFFu) + (int)(e.jwl & 0xFFu);
+    const int src = kc & 15, sl = (kc >> 4) & 3;
+    uint32_t a[GS], tl[GS], th[GS];
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
-        if (s < e.nslots) {
-            const uint32_t kb = e.kB[s], js = e.jw[s];
-            const int j = (int)(kb & 0xFFu), nj = (int)(js & 0xFFu), d = e.due[s];
-            const bool valid = ((kb >> 24) & 2u) != 0;
-            const bool in = valid && nj <= j;                         // the job's stage-j task is still unassigned
-            const double est = td + e.tsum[s];                        // :136,139 with task_index 0
-            p.de[s] = est - (double)d;
-            p.da[s] = e.t - d;                                        // :138
-            p.in[s] = in;
-            p.late[s] = in && e.t > d;                                // :134-135
-            p.cnte[s] = in && est > (double)d;                        // :136-137
-            p.wait[s] = in && nj == j && (js >> 8) != kNoSeq;         // head of job_now_list[(r, j)]
-        } else {
-            p.de[s] = 0.0; p.da[s] = 0; p.in[s] = false; p.late[s] = false; p.cnte[s] = false; p.wait[s] = false;
+        a[s] = 0; tl[s] = 0; th[s] = 0;
+        if (SLOT_ON(e, s)) {
+            a[s] = greadu(e.em[s], src, e.gb);
+            tl[s] = greadu((uint32_t)__double2loint(e.tsum[s]), src, e.gb);
+            th[s] = greadu((uint32_t)__double2hiint(e.tsum[s]), src, e.gb);
         }
+    }
+    e.emc = pick_slot(a, sl);
+    e.tsumc = __hiloint2double((int)pick_slot(th, sl), (int)pick_slot(tl, sl));
+    e.rsumc = 0.0;
+    if (want_rsum) {
+        uint32_t rl[GS], rh[GS];
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            rl[s] = 0; rh[s] = 0;
+            if (SLOT_ON(e, s)) {
+                rl[s] = greadu((uint32_t)__double2loint(e.rsum[s]), src, e.gb);
+                rh[s] = greadu((uint32_t)__double2hiint(e.rsum[s]), src, e.gb);
+            }
+        }
+        e.rsumc = __hiloint2double((int)pick_slot(rh, sl), (int)pick_slot(rl, sl));
     }
 }
 
@@ -180,73 +204,78 @@ GDEV void g_params(const GE<V> &e, GP &p) {
 template <int V>
 GDEV int g_rng(GE<V> &e, bool take, int n) {
     const uint64_t u = splitmix64(e.env_seed + (uint64_t)e.rng_calls);
-    if (take) e.rng_calls++;
-    return (int)(((u >> 32) * (uint64_t)(uint32_t)n) >> 32);
+    e.rng_calls += take ? 1u : 0u;
+    return (int)__umulhi((uint32_t)(u >> 32), (uint32_t)n);
 }
 
-// SO_FJSSP.py:267-298 task_select for every row with go; returns k or -1 (status set)
+// SO_FJSSP.py:267-298 task_select for every row with go, on the job lanes: a job's current operation type is available
+// when the job waits (it carries a FIFO sequence) and an eligible machine is idle; the lists the reference builds in
+// kind_task_tuple order are, restricted to those, in job order.  Every rule is "the first candidate of the largest
+// key".  Returns the chosen JOB lane or -1 (status set).
 template <int V>
-GDEV int g_task_select(GE<V> &e, const GP &p, bool go, int a0, uint32_t idle) {
-    bool av[GS], fav[GS], C[GS];
-    bool anyav_l = false, anyfav_l = false;
-#pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        av[s] = p.wait[s] && (e.em[s] & idle) != 0;
-        fav[s] = p.wait[s] && ((e.em[s] >> 8) & idle) != 0;
-        anyav_l = anyav_l || av[s]; anyfav_l = anyfav_l || fav[s];
+GDEV int g_task_select(GE<V> &e, bool go, int a0, uint32_t idle) {
+    const bool waiting = e.jwl < kSeqNone;
+    const bool av = waiting && (e.emc & idle) != 0, fav = waiting && (e.emc & (idle << 8)) != 0;
+    const uint32_t avm = gballot(av, e.gb), favm = gballot(fav, e.gb);
+    e.status |= (go && avm == 0) ? (uint32_t)FJSP_ST_NO_EVENT : 0u;
+    e.status |= (go && avm != 0 && a0 >= 6) ? (uint32_t)FJSP_ST_BAD_TASK_RULE : 0u;          // MyError :297
+    const bool run = go && avm != 0 && a0 < 6;
+    // update_parameter for a list of one (:126-154): estimated delay = max_e = urgency, actual delay = max_a
+    const double de = ((double)e.t + e.tsumc) - (double)e.duej;          // :136,139 with task_index 0
+    const int da = e.t - e.duej;                                         // :138
+    const bool pre = av && (a0 == 0 ? de > 0.0 : (a0 == 1 && da > 0));   // rules 1, 2: the delayed types first (:269-278)
+    const uint32_t prem = gballot(pre, e.gb);
+    bool C = av;
+    C = (a0 <= 1 && prem != 0) ? pre : C;
+    C = (a0 >= 2 && a0 <= 4 && favm != 0) ? fav : C;                     // rules 3-5: the fluid-available types first (:279-293)
+    uint64_t key = sortable(de);
+    if (wave_any(run && a0 == 2)) {
+        const double fq = 1.0 - e.rsumc * (double)e.t;                   // fluid_unprocessed_number (:239-240), Q0 = 1 job
+        key = a0 == 2 ? sortable(1.0 - fq) : key;                        // Tasks.gap class_FJSSP.py:70-72 (one unprocessed task)
     }
-    const bool anyav = gballot(anyav_l, e.gb) != 0, anyfav = gballot(anyfav_l, e.gb) != 0;
-    const bool noev = go && !anyav;
-    if (noev) e.status |= FJSP_ST_NO_EVENT;
-    const bool bad = go && anyav && a0 >= 6;
-    if (bad) e.status |= FJSP_ST_BAD_TASK_RULE;                           // MyError :297
-    const bool run = go && anyav && a0 < 6;
-    // rules 1 and 2 prefer the types with an estimated / actual delay when any is available (:269-278)
-    bool pre_l = false;
-#pragma unroll
-    for (int s = 0; s < GS; ++s) pre_l = pre_l || (av[s] && (a0 == 0 ? p.cnte[s] : p.late[s]));
-    const bool anypre = gballot(pre_l && a0 <= 1, e.gb) != 0;
-    const double dt = (double)e.t;                                        // gap_time (:237), one order: order_arrive_time = 0
-    uint64_t key[GS], best = 0;
-#pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        bool c;
-        uint64_t kv;
-        if (a0 == 0) { c = anypre ? (av[s] && p.cnte[s]) : av[s]; kv = sortable(p.de[s]); }                 // :269-273
-        else if (a0 == 1) { c = anypre ? (av[s] && p.late[s]) : av[s]; kv = anypre ? sortable_max_i32(p.da[s]) : sortable(p.de[s]); }
-        else if (a0 == 2) {                                                                                   // :279-283
-            c = anyfav ? fav[s] : av[s];
-            const double fq = 1.0 - e.rsum[s] * dt;                       // fluid_unprocessed_number (:239-240), Q0 = 1 job
-            kv = sortable((p.in[s] ? 1.0 : 0.0) - fq);                    // Tasks.gap class_FJSSP.py:70-72
-        } else if (a0 == 3) { c = anyfav ? fav[s] : av[s]; kv = sortable(p.de[s]); }                         // :284-288
-        else if (a0 == 4) { c = anyfav ? fav[s] : av[s]; kv = sortable_min_i32(e.due[s]); }                  // :289-293
-        else { c = av[s]; kv = 0; }                                                                           // :294-295
-        C[s] = c && run;
-        key[s] = C[s] ? kv : 0ull;
-        best = max(best, key[s]);
-    }
-    const uint64_t ext = gmax64(best);
-    bool hit[GS];
-#pragma unroll
-    for (int s = 0; s < GS; ++s) hit[s] = C[s] && key[s] == ext;
+    key = (a0 == 1 && prem != 0) ? sortable_max_i32(da) : key;           // :274-278
+    key = a0 == 4 ? sortable_min_i32(e.duej) : key;                      // :289-293
+    key = a0 == 5 ? 0ull : key;
+    int r = first_max(C && run, key, e.gb);
     if (wave_any(run && a0 == 5)) {
-        // random.choice(task_available_list): the idx-th available type in kind_task_tuple order
-        const uint32_t m0 = gballot(av[0], e.gb), m1 = gballot(av[1], e.gb), m2 = gballot(av[2], e.gb), m3 = gballot(av[3], e.gb);
-        const uint64_t avm = (uint64_t)(m0 | (m1 << 16)) | ((uint64_t)(m2 | (m3 << 16)) << 32);
+        // random.choice(task_available_list) (:294-295): the idx-th available job
         const bool rnd = run && a0 == 5;
-        const int idx = g_rng(e, rnd, __builtin_popcountll(avm));
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            const int k = 16 * s + e.l;
-            const int rank = __builtin_popcountll(avm & ((1ull << k) - 1ull));
-            if (rnd) hit[s] = av[s] && rank == idx;
-        }
+        const int idx = g_rng(e, rnd, __builtin_popcount(avm));
+        const uint32_t pick = gballot(av && __builtin_popcount(avm & ((1u << e.l) - 1u)) == idx, e.gb);
+        r = rnd ? (int)__builtin_ctz(pick | 0x10000u) : r;
     }
-    int kc = kNone;
-#pragma unroll
-    for (int s = GS - 1; s >= 0; --s) kc = hit[s] ? 16 * s + e.l : kc;
-    const int k = gmin(kc);
-    return (run && k != kNone) ? k : -1;
+    return (run && r < 16) ? r : -1;
+}
+
+// Strictly sequential float sum of n8 (a multiple of 8, >= 8, wave-uniform) operands of an LDS row, left to right like the
+// reference's sum(): the ring of fjsp_common.h's lds_chain_sum_ring8 (eight 16-byte registers, each refilled 16 elements
+// ahead) with ONE counted wait per two registers -- LDS reads return in order, so lgkmcnt(6) with eight reads in flight says
+// the two oldest have landed -- which takes the walk from 2.8 to 1.9 instructions per element.  Reads up to 16 entries past n8
+// (never consumed): rows are followed by at least 128 bytes of the same allocation.
+#define FJSP_LDS_WAIT2(r0, r1, cnt) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(cnt))
+GDEV double row_chain_sum(const double *src, int n8) {
+    double acc = 0.0;
+    uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(src);      // the low half of a flat LDS address is the LDS offset
+    const int n = __builtin_amdgcn_readfirstlane(n8);
+    fjsp_d2 A0, A1, A2, A3, A4, A5, A6, A7;
+    FJSP_LDS_READ128(A0, a, 0); FJSP_LDS_READ128(A1, a, 16); FJSP_LDS_READ128(A2, a, 32); FJSP_LDS_READ128(A3, a, 48);
+    FJSP_LDS_READ128(A4, a, 64); FJSP_LDS_READ128(A5, a, 80); FJSP_LDS_READ128(A6, a, 96); FJSP_LDS_READ128(A7, a, 112);
+    int i = 0;
+#define FJSP_RING_PAIR(R0, R1, off)                                                        \
+    FJSP_LDS_WAIT2(R0, R1, 6);                                                             \
+    acc = acc + R0.x; acc = acc + R0.y; acc = acc + R1.x; acc = acc + R1.y;                \
+    FJSP_LDS_READ128(R0, a, off); FJSP_LDS_READ128(R1, a, off + 16);
+    for (; i + 16 <= n; i += 16) {
+        FJSP_RING_PAIR(A0, A1, 128) FJSP_RING_PAIR(A2, A3, 160) FJSP_RING_PAIR(A4, A5, 192) FJSP_RING_PAIR(A6, A7, 224)
+        a += 128;
+    }
+#undef FJSP_RING_PAIR
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(A4), "+v"(A5), "+v"(A6), "+v"(A7));
+    if (i < n) {                         // n is a multiple of 8: eight operands left, in the first half of the ring
+        acc = acc + A0.x; acc = acc + A0.y; acc = acc + A1.x; acc = acc + A1.y;
+        acc = acc + A2.x; acc = acc + A2.y; acc = acc + A3.x; acc = acc + A3.y;
+    }
+    return acc;
 }
 
 // Strictly sequential sums out of the LDS rows: lanes with `walk` sum n8w entries of their row (rows are zero padded to
@@ -254,150 +283,174 @@ GDEV int g_task_select(GE<V> &e, const GP &p, bool go, int a0, uint32_t idle) {
 template <int V>
 GDEV double g_walk(const GE<V> &e, bool walk, int row) {
     double sm = 0.0;
-    if (wave_any(walk)) sm = lds_chain_sum_ring8(e.rows + (walk ? row : 0) * e.ks, e.n8w);
+    if (wave_any(walk)) sm = row_chain_sum(e.rows + (walk ? row : 0) * KS, e.n8w);
     return sm;
 }
 
-// Machine.gap_ave (class_FJSSP.py:144-146) of the machines in `cand` for the rows with `need`: a strictly sequential
-// sum over kind_task_tuple order of unprocessed - fluid_unprocessed of the machine's operation types, divided by
-// (n + 1e-18).  Lane (s, l) writes the gap of its operation type on every candidate machine to that machine's LDS row
-// (+0.0 where the type cannot run there: an exact identity of the running sum); machine lane m walks row m.  Returns
-// the machine lanes' gap_ave.
-template <int V>
-GDEV double g_gap_ave(const GE<V> &e, const DevBatch &b, bool need, uint32_t cand) {
-    const double dt = (double)e.t;
-    const double *col = reinterpret_cast<const double *>(e.ir + b.L.i_col);
-    const int MP = e.MP;
+// Request the {arrival, rate} rows of every slot of the rows with `need` (class_FJSSP.py:144-146 reads all of them)
+template <int V, int MPC>
+GDEV void g_cols_issue(const GE<V> &e, const DevBatch &b, bool need, GCols<MPC> &cr) {
+    const double2 *col = reinterpret_cast<const double2 *>(e.ir + b.L.i_col);
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
-        if (s < e.nslots) {
-            const int k = 16 * s + e.l;
-            const uint32_t elig = e.em[s] & 0xFFu;
+#pragma unroll
+        for (int m = 0; m < MPC; ++m) cr.c[s][m] = make_double2(0.0, 0.0);
+        if (SLOT_ON(e, s) && need) {
+            const double2 *rowk = col + (16 * s + e.l) * e.MP;
+#pragma unroll
+            for (int m = 0; m < MPC; ++m)
+                if (m < e.MP) cr.c[s][m] = rowk[m];
+        }
+    }
+}
+// Machine.gap_ave's operands (class_FJSSP.py:137-146): lane (s, l) writes unprocessed - fluid_unprocessed of its
+// operation type on machine m to LDS row m.  The (k, m) entries of types that cannot run on m hold arrival = rate = 0
+// (fluid_tables_kernel), so their gap is 0.0 - (0.0 - dt * 0.0) = +0.0 -- an exact identity of the running sum, like
+// the padding beyond K -- and no eligibility test is needed.
+template <int V, int MPC>
+GDEV void g_gap_rows(const GE<V> &e, bool need, const GCols<MPC> &cr) {
+    const double dt = (double)e.t;
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+        if (SLOT_ON(e, s) && need) {
             const uint32_t asg = (e.asgw >> (8 * s)) & 0xFFu;
-            for (int m = 0; m < MP; ++m) {
-                const bool row_on = need && ((cand >> m) & 1u);
-                const bool on = row_on && ((elig >> m) & 1u);
-                double g = 0.0;
-                if (on) {
-                    const double2 ar = *reinterpret_cast<const double2 *>(col + 2 * (k * MP + m));
-                    // (unprocessed = arrival, less one where this type was assigned to m: class_FJSSP.py:198, :304)
-                    const double un = asg == (uint32_t)m ? ar.x - 1.0 : ar.x;
-                    g = un - (ar.x - dt * ar.y);
-                }
-                if (row_on && k < e.n8w) e.rows[m * e.ks + k] = g;      // (rows are n8w entries long: no spill into the next row)
+            double *dst = e.rows + 16 * s + e.l;
+#pragma unroll
+            for (int m = 0; m < MPC; ++m) {
+                const double2 ar = cr.c[s][m];
+                // (unprocessed = arrival, less one where this type was assigned to m: class_FJSSP.py:198, :304)
+                const double un = asg == (uint32_t)m ? ar.x - 1.0 : ar.x;
+                dst[m * KS] = un - (ar.x - dt * ar.y);
             }
         }
     }
-    lds_sync();
-    const bool walk = need && e.l < e.M && ((cand >> e.l) & 1u);
-    const double sm = g_walk<V>(e, walk, e.l);
-    lds_sync();
-    return sm / ((double)e.mcnt + 1e-18);
 }
 
-template <class T>
-GDEV T pick_slot(const T (&a)[GS], int s) {
-    const T lo = (s & 1) ? a[1] : a[0], hi = (s & 1) ? a[3] : a[2];
-    return (s & 2) ? hi : lo;
+// The same with the rows fetched here, slot by slot (large batches: the registers of GCols would cost resident waves, and it is
+// the resident waves that hide the memory there)
+template <int V, int MPC>
+GDEV void g_gap_rows_late(const GE<V> &e, const DevBatch &b, bool need) {
+    const double dt = (double)e.t;
+    const double2 *col = reinterpret_cast<const double2 *>(e.ir + b.L.i_col);
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+        if (SLOT_ON(e, s) && need) {
+            const uint32_t asg = (e.asgw >> (8 * s)) & 0xFFu;
+            const double2 *rowk = col + (16 * s + e.l) * e.MP;
+            double *dst = e.rows + 16 * s + e.l;
+            double2 ar[MPC];
+#pragma unroll
+            for (int m = 0; m < MPC; ++m) ar[m] = m < e.MP ? rowk[m] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int m = 0; m < MPC; ++m) {
+                const double un = asg == (uint32_t)m ? ar[m].x - 1.0 : ar[m].x;
+                dst[m * KS] = un - (ar[m].x - dt * ar[m].y);
+            }
+        }
+    }
 }
 
 // SO_FJSSP.py:300-322 / MO_FJSSP_discretes.py:209-230 machine_select for the rows with `go`.  Machine ids < 8: every
 // CPython set involved iterates in ascending order (fjsp_pyset.h), the candidate lists are bit masks and "first
-// extremum wins" is the lowest machine lane that attains it.  Returns m or -1 (status set); *pm_out its processing time.
+// extremum wins" is the lowest machine lane that attains it.  gap_rows: the rows whose LDS rows hold Machine.gap_ave's
+// operands.  Returns m or -1 (status set); *pm_out its processing time.
 template <int V>
-GDEV int g_machine_select(GE<V> &e, const DevBatch &b, bool go, int a1, int k_sel, uint32_t em_sel, uint32_t idle, int *pm_out) {
-    const uint32_t sel = idle & em_sel & 0xFFu, fsel = idle & (em_sel >> 8) & 0xFFu;
-    const bool noev = go && sel == 0;
-    if (noev) e.status |= FJSP_ST_NO_EVENT;
+GDEV int g_machine_select(GE<V> &e, const DevBatch &b, bool go, int a1, int k_sel, uint32_t em_sel, uint32_t idle, bool gap_rows,
+                          int *pm_out) {
     constexpr bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES;
+    const uint32_t sel = idle & em_sel, fsel = idle & (em_sel >> 8);         // (idle has the low 8 bits only)
+    e.status |= (go && sel == 0) ? (uint32_t)FJSP_ST_NO_EVENT : 0u;
     const bool bad = go && sel != 0 && a1 >= (is_mo ? 3 : 5);
-    if (bad) e.status |= FJSP_ST_BAD_MACHINE_RULE;                        // MyError :321
+    e.status |= bad ? (uint32_t)FJSP_ST_BAD_MACHINE_RULE : 0u;                // MyError :321
     const bool run = go && sel != 0 && !bad;
-    // lane m: gap_rj_dict[m][k_sel] (class_FJSSP.py:137-142) and p[m][k_sel]; op-major layout: the column of k_sel is MP
-    // contiguous entries per array
     const uint32_t fl = fsel ? fsel : sel;
-    enum { GAP, PT, GAVE, RND };
-    int mode;
+    // per row: candidate list C and the kind of key (largest gap / least time / largest gap_ave / random)
+    bool m_pt, m_gave, m_rnd;
     uint32_t C;
-    if (is_mo) {
-        mode = a1 == 0 ? (fsel ? GAP : PT) : (a1 == 1 ? GAVE : GAP);                                           // :213-227
-        C = a1 == 0 ? (fsel ? fsel : sel) : fl;
-    } else {
-        mode = a1 <= 1 ? GAP : (a1 == 2 ? PT : (a1 == 3 ? GAVE : RND));                                         // :304-319
+    if (is_mo) {                                                              // MO_FJSSP_discretes.py:213-227
+        m_pt = a1 == 0 && fsel == 0; m_gave = a1 == 1; m_rnd = false;
+        C = fl;
+    } else {                                                                  // SO_FJSSP.py:304-319
+        m_pt = a1 == 2; m_gave = a1 == 3; m_rnd = a1 == 4;
         C = (a1 == 0 || a1 == 3) ? fl : sel;
     }
-    if (!run) C = 0;
-    const bool mem = e.l < 8 && ((C >> e.l) & 1u);
+    C = run ? C : 0u;
+    const bool mem = ((C >> e.l) & 1u) != 0;            // (C has bits below 8 only)
     int pm = 0;
     double g = 0.0;
-    if (run && e.l < 8 && ((sel >> e.l) & 1u)) {
+    if (((run ? sel : 0u) >> e.l) & 1u) {
+        // lane m: p[m][k_sel] and gap_rj_dict[m][k_sel] (class_FJSSP.py:137-142); op-major layout: the column of k_sel is MP
+        // contiguous entries per array.  k_sel has not been dispatched yet -- it is available -- so its unprocessed is
+        // its arrival
         const int o = k_sel * e.MP + e.l;
         pm = reinterpret_cast<const uint16_t *>(e.ir + b.L.i_p)[o];
-        const double2 ar = *reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(e.ir + b.L.i_col) + 2 * o);
-        // (k_sel has not been dispatched yet -- it is available -- so its unprocessed is its arrival)
+        const double2 ar = reinterpret_cast<const double2 *>(e.ir + b.L.i_col)[o];
         g = ar.x - (ar.x - (double)e.t * ar.y);
     }
-    uint64_t key = mode == PT ? sortable_min_i32(pm) : sortable(g);
-    const bool need3 = run && mode == GAVE && (C & (C - 1)) != 0;         // (a list of one is returned without ranking it)
+    const bool need3 = m_gave && gap_rows && (C & (C - 1)) != 0;     // (a list of one is returned without ranking it)
     if (wave_any(need3)) {
-        const double gave = g_gap_ave<V>(e, b, need3, C);
-        if (need3) key = sortable(gave);
+        // Machine.gap_ave (class_FJSSP.py:144-146): the strictly sequential sum of the machine's row / (n + 1e-18)
+        const double sm = g_walk<V>(e, need3 && e.l < e.M, e.l);
+        g = need3 ? sm / ((double)e.mcnt + 1e-18) : g;
     }
-    if (mode == GAVE && !need3) key = 0;
-    if (!mem) key = 0;
-    const uint64_t ext = gmax64(key);
-    bool hit = mem && key == ext;
-    if (wave_any(run && mode == RND)) {
-        const bool rnd = run && mode == RND;
-        const int idx = g_rng(e, rnd, __builtin_popcount(sel));
-        if (rnd) hit = mem && __builtin_popcount(C & ((1u << e.l) - 1u)) == idx;                                 // :318-319
+    uint64_t key = sortable(g);
+    key = m_pt ? sortable_min_i32(pm) : key;
+    key = (m_rnd || (m_gave && !need3)) ? 0ull : key;   // no ranking: every member ties
+    int m = first_max(mem, key, e.gb);
+    if (wave_any(run && m_rnd)) {
+        const bool rnd = run && m_rnd;
+        const int idx = g_rng(e, rnd, __builtin_popcount(sel));                                                   // :318-319
+        const uint32_t pick = gballot(mem && __builtin_popcount(C & ((1u << e.l) - 1u)) == idx, e.gb);
+        m = rnd ? (int)__builtin_ctz(pick | 0x10000u) : m;
     }
-    const int m = gmin(hit ? e.l : kNone);
-    const bool ok = run && m != kNone;
+    const bool ok = run && m < 16;
     *pm_out = gread(pm, ok ? m : 0, e.gb);
     return ok ? m : -1;
 }
 
-// SO_FJSSP.py:176-250: dispatch the job of k_sel on m_sel, then advance the clock until some operation type is
-// available again (or the episode ends), for the rows with `go`.
+// SO_FJSSP.py:176-250: dispatch job r_sel (its current operation type k_sel) on m_sel, then advance the clock until some
+// operation type is available again (or the episode ends), for the rows with `go`.  The event loop runs on the job and
+// machine lanes alone.
 template <int V>
-GDEV void g_dispatch_advance(GE<V> &e, bool go, int k_sel, int m_sel, int pm, uint32_t kb_sel, int due_sel) {
-    const int j_sel = (int)(kb_sel & 0xFFu), Jr = (int)((kb_sel >> 8) & 0xFFu), r_sel = (int)((kb_sel >> 16) & 0xFFu);
+GDEV void g_dispatch_advance(GE<V> &e, bool go, int r_sel, int k_sel, int m_sel, int pm) {
+    // the job's word, first operation | J_r, due date: from its lane
+    const int rs = go ? r_sel : 0;
+    const uint32_t jw_sel = greadu(e.jwl, rs, e.gb), ji_sel = greadu(e.jinfo, rs, e.gb);
+    const int due_sel = gread(e.duej, rs, e.gb);
+    // elig | fmask of the job's NEXT operation type (k_sel + 1): what the event loop tests once the job waits again
+    const int kn = (k_sel + 1) & 63;
+    const uint32_t em_next = greadu(pick_slot(e.em, kn >> 4), kn & 15, e.gb);
+    const int nj = (int)(jw_sel & 0xFFu) + 1, Jr = (int)((ji_sel >> 8) & 0xFFu);   // the job is at stage nj - 1; it moves on
+    const bool last = nj == Jr;
     const int time_end = e.t + pm;                                           // :184
-    const int nj = j_sel + 1;                // the job of (r, j) is at stage j; it moves to j + 1
-    const uint32_t word = jst_pack(kNoSeq, (uint32_t)nj);
-    if (go && e.l == r_sel) e.jwl = word;                                    // :186-191
+    const bool jmine = go && e.l == r_sel;
+    e.jwl = jmine ? jst_pack(kNoSeq, (uint32_t)nj) : e.jwl;                  // :186-191
+    e.emc = jmine ? em_next : e.emc;
+    const int ksel_go = go ? k_sel : -1;
 #pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        if (go && (int)((e.kB[s] >> 16) & 0xFFu) == r_sel) e.jw[s] = word;
-        if (go && k_sel == 16 * s + e.l) e.asgw = (e.asgw & ~(0xFFu << (8 * s))) | ((uint32_t)m_sel << (8 * s));   // :198
-    }
+    for (int s = 0; s < GS; ++s)      // :198 unprocessed_rj_dict[m][(r, j)] -= 1, kept as "the machine this type was assigned to"
+        e.asgw = ksel_go == 16 * s + e.l ? ((e.asgw & ~(0xFFu << (8 * s))) | ((uint32_t)m_sel << (8 * s))) : e.asgw;
     // machine lane: time_end, and job | (k of the job's next stage + 1) << 16 (0 in the high half: no further stage)
-    if (go && e.l == m_sel) { e.tend = time_end; e.mjob = r_sel | ((nj == Jr ? 0 : k_sel + 2) << 16); }            // :194-197
-    if (go) {
-        e.busy |= 1u << m_sel;
-        e.completion = max(e.completion, time_end);
-        if (nj == Jr) {                                                      // :200-202
-            e.n_un--;
-            const int late = time_end - due_sel;
-            e.tard_done += late > 0 ? late : 0;
-        }
+    const bool mine = go && e.l == m_sel;
+    e.tend = mine ? time_end : e.tend;                                       // :194-197
+    e.mjob = mine ? (r_sel | ((last ? 0 : k_sel + 2) << 16)) : e.mjob;
+    e.busy |= go ? 1u << (m_sel & 31) : 0u;
+    e.completion = go ? max(e.completion, time_end) : e.completion;
+    {                                                                        // :200-202
+        const int late = time_end - due_sel;
+        e.n_un -= (go && last) ? 1 : 0;
+        e.tard_done += (go && last && late > 0) ? late : 0;
     }
     bool act = go;
     for (;;) {
         const uint32_t idle = ~e.busy & e.mmask;
-        bool av_l = false;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) {
-            const uint32_t kb = e.kB[s], js = e.jw[s];
-            const bool wait = ((kb >> 24) & 2u) && (js & 0xFFu) == (kb & 0xFFu) && (js >> 8) != kNoSeq;
-            av_l = av_l || (wait && (e.em[s] & idle & 0xFFu) != 0);
-        }
-        act = act && gballot(av_l, e.gb) == 0;                               // :204
+        act = act && gballot(e.jwl < kSeqNone && (e.emc & idle) != 0, e.gb) == 0;   // :204
         if (!wave_any(act)) break;
         const int tn = gmin((e.l < e.M && e.tend > e.t) ? e.tend : 0x7fffffff);   // :205-207 next event
-        if (act && tn == 0x7fffffff) { e.status |= FJSP_ST_NO_EVENT; act = false; }
-        if (act) e.t = tn;
+        const bool noev = act && tn == 0x7fffffff;
+        e.status |= noev ? (uint32_t)FJSP_ST_NO_EVENT : 0u;
+        act = act && !noev;
+        e.t = act ? tn : e.t;
         // :209-215 completions in ascending machine order: the job goes to the FIFO of its next stage (if any)
         const bool rel = act && e.l < e.M && e.tend == tn && (e.mjob >> 16) != 0;
         const uint32_t relm = gballot(rel, e.gb);
@@ -405,83 +458,93 @@ GDEV void g_dispatch_advance(GE<V> &e, bool go, int k_sel, int m_sel, int pm, ui
         // every releasing machine lane hands its job lane the job's place in the append order (ds_permute: a push; the
         // other lanes push a zero to lane 15, which is no job lane -- at most 15 jobs)
         const int got = __builtin_amdgcn_ds_permute((e.gb + (rel ? (e.mjob & 0xFFFF) : 15)) << 2, rel ? rank + 1 : 0);
-        if (got != 0 && e.l < 15) e.jwl = (e.jwl & 0xFFu) | ((e.seq_ctr + (uint32_t)got - 1u) << 8);
+        e.jwl = (got != 0 && e.l < 15) ? ((e.jwl & 0xFFu) | ((e.seq_ctr + (uint32_t)got - 1u) << 8)) : e.jwl;
         e.seq_ctr += (uint32_t)__builtin_popcount(relm);
-        g_refresh_jw<V>(e);
         const uint32_t freed = gballot(e.l < e.M && e.tend <= e.t, e.gb);   // :233-235
-        if (act) {
-            e.busy &= ~freed;
-            if (e.n_un == 0) { e.done = 1; act = false; }                    // :247-250
-        }
+        e.busy &= act ? ~freed : 0xFFFFFFFFu;
+        const bool fin = act && e.n_un == 0;                                 // :247-250
+        e.done = fin ? 1 : e.done;
+        act = act && !fin;
     }
 }
 
-// SO_FJSSP.py:78-97 state_extract (+ the ratios of update_parameter :156-165) of the rows with `on` at the current
-// clock; g_params must be current.  Returns the observation in the observation lanes (lane (8 + i) & 15 holds entry i)
-// and delay_time_sum_unprocessed (:110-122) through *tard_unproc.  stats_only: a step that hands no state back needs
-// the tardiness for its reward and nothing else.
+// SO_FJSSP.py:78-97 state_extract and update_parameter's statistics (:99-166) at the current clock.  Returns the
+// observation in the observation lanes (lane (8 + i) & 15 holds entry i) and delay_time_sum_unprocessed (:110-122)
+// through *tard_unproc; only the rows with `on` walk their sums (the others' results are garbage nobody reads).
+// stats_only: a step that hands no state back needs the tardiness for its reward and nothing else.
 template <int V>
-GDEV double g_observe(const GE<V> &e, const GP &p, bool on, bool stats_only, long long *tard_unproc) {
+GDEV double g_observe(const GE<V> &e, bool on, bool stats_only, long long *tard_unproc) {
     using P = ObsPos<V>;
     constexpr int L_ave0 = (P::ave0 + 8) & 15, L_ave1 = (P::ave1 + 8) & 15, L_ave2 = (P::ave2 + 8) & 15;
     constexpr int L_sd0 = (P::sd0 + 8) & 15, L_sd1 = (P::sd1 + 8) & 15, L_sd2 = (P::sd2 + 8) & 15;
-    // ---- integer statistics (order-free): packed row sums
-    uint32_t c1 = 0, c2 = 0, c3 = 0;
+    // ---- per job (lists of one, :126-154): operations left, lateness; packed row sums
+    //   c1 = tasks | delay_a << 8 | job_a << 16 | delay_e << 24      c2 = tardiness, low 16 bits      c3 = high bits | job_e << 24
+    const uint32_t Jr = (e.jinfo >> 8) & 0xFFu, njl = e.jwl & 0xFFu;
+    const uint32_t rem = njl < Jr ? Jr - njl : 0u;                  // (lanes beyond njobs: J_r = 0)
+    const bool latej = e.t > e.duej;                                // :134-135 (:120-122 for the last stage)
+    const uint32_t tl = (latej && rem != 0) ? (uint32_t)(e.t - e.duej) : 0u;
+    uint32_t c1 = rem + (latej ? rem << 8 : 0u) + ((latej && rem != 0) ? 1u << 16 : 0u);
+    uint32_t c2 = tl & 0xFFFFu, c3 = tl >> 16;
+    *tard_unproc = 0;
+    if (stats_only) {
+        c2 = (uint32_t)gsum((int)c2); c3 = (uint32_t)gsum((int)c3);
+        *tard_unproc = (long long)c2 + ((long long)c3 << 16);
+        return 0.0;
+    }
+    // ---- per operation type: is it unassigned (stage of its job <= its own), its estimated delay (:136-137), its
+    // gap_rate row entry; finish_rate is 0 or 1 here and the machines' time_end are integers: their left-to-right f64 sums
+    // are exact, i.e. equal to the integer sums; gap_rate's sum is walked
+    const double td = (double)e.t;
+    bool in[GS];
+    double grv[GS];
+    uint32_t q0h[GS];
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
-        if (s < e.nslots) {
-            const bool last = ((e.kB[s] >> 24) & 1u) != 0;
-            const uint32_t tl = (last && p.late[s]) ? (uint32_t)p.da[s] : 0u;                 // :120-122
-            c1 += (p.in[s] ? 1u : 0u) | (p.late[s] ? 1u << 8 : 0u) | (p.cnte[s] ? 1u << 16 : 0u) | ((last && p.late[s]) ? 1u << 24 : 0u);
-            c2 += ((last && p.cnte[s]) ? 1u : 0u) | ((tl & 0xFFFFu) << 8);
-            c3 += tl >> 16;
+        in[s] = false; grv[s] = 0.0; q0h[s] = 0;
+        if (SLOT_ON(e, s)) {
+            const uint32_t kb = e.kB[s];
+            const uint32_t njk = greadu(e.jwl, (int)((kb >> 16) & 0xFu), e.gb) & 0xFFu;
+            in[s] = njk <= (kb & 0xFFu);
+            const double de = (td + e.tsum[s]) - (double)e.due[s];
+            const bool cnte = in[s] && de > 0.0;
+            c1 += cnte ? 1u << 24 : 0u;
+            c3 += (cnte && ((kb >> 24) & 1u)) ? 1u << 24 : 0u;
+            q0h[s] = (kb >> 24) & 2u ? 0x3FF00000u : 0u;                                // Q0 = jobs of the kind: 1.0, or 0.0 for padding
+            const double q0 = __hiloint2double((int)q0h[s], 0);
+            const double fq = q0 - e.rsum[s] * td;                                      // fluid_unprocessed_number (:239-240)
+            grv[s] = (in[s] ? 1.0 : 0.0) - fq;                                          // gap_rate class_FJSSP.py:66-68 (x / 1.0 == x)
+            e.rows[16 * s + e.l] = grv[s];
         }
     }
     c1 = (uint32_t)gsum((int)c1); c2 = (uint32_t)gsum((int)c2); c3 = (uint32_t)gsum((int)c3);
-    const int tasks = (int)(c1 & 0xFFu), delay_a = (int)((c1 >> 8) & 0xFFu), delay_e = (int)((c1 >> 16) & 0xFFu), job_a = (int)(c1 >> 24);
-    const int job_e = (int)(c2 & 0xFFu);
-    *tard_unproc = (long long)(c2 >> 8) + ((long long)c3 << 16);
-    if (stats_only) return 0.0;
-    const int jobs = e.n_un;
-    // ---- first pass: the three means.  finish_rate is 0 or 1 here (one job per kind) and the machines' time_end are
-    // integers: their left-to-right f64 sums are exact, i.e. equal to the integer sums; gap_rate's is walked.
-    const double dt = (double)e.t;
-    double frv[GS], grv[GS];
-#pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        if (s < e.nslots) {
-            const bool valid = ((e.kB[s] >> 24) & 2u) != 0;
-            const double fq = 1.0 - e.rsum[s] * dt;                               // fluid_unprocessed_number, Q0 = 1 (:239-240)
-            frv[s] = (valid && !p.in[s]) ? 1.0 : 0.0;                             // finish_rate class_FJSSP.py:74-76 ((1 - nun) / 1)
-            grv[s] = valid ? (p.in[s] ? 1.0 : 0.0) - fq : 0.0;                    // gap_rate class_FJSSP.py:66-68 (x / 1.0 == x)
-            if (on && 16 * s + e.l < e.n8w) e.rows[16 * s + e.l] = grv[s];
-        } else { frv[s] = 0.0; grv[s] = 0.0; }
-    }
+    const int tasks = (int)(c1 & 0xFFu), delay_a = (int)((c1 >> 8) & 0xFFu), job_a = (int)((c1 >> 16) & 0xFFu), delay_e = (int)(c1 >> 24);
+    const int job_e = (int)(c3 >> 24), jobs = e.n_un;
+    *tard_unproc = (long long)c2 + ((long long)(c3 & 0xFFFFFFu) << 16);
     const uint32_t tlo = (uint32_t)gsum((e.l < e.M) ? (e.tend & 0xFFFF) : 0), thi = (uint32_t)gsum((e.l < e.M) ? (int)((uint32_t)e.tend >> 16) : 0);
     const double tsum_td = (double)(((long long)thi << 16) + (long long)tlo);
     lds_sync();
     const double cs1 = g_walk<V>(e, on && e.l == L_ave1, 0);
     lds_sync();
-    double num = 0.0, den = 1.0;
-    if (e.l == L_ave0) { num = (double)(e.K - tasks); den = (double)e.K; }
-    if (e.l == L_ave1) { num = cs1; den = (double)e.K; }
-    if (e.l == L_ave2) { num = tsum_td; den = (double)e.M; }
-    {
-        const int q = ((e.l - 8) & 15) - P::ratio0;                               // :156-165
-        if (q >= 0 && q < 4) {
-            num = (double)(q == 0 ? delay_a : (q == 1 ? delay_e : (q == 2 ? job_a : job_e)));
-            den = (double)(q < 2 ? tasks : jobs);
-        }
-    }
-    const double q1 = num / den;
+    const int oi = (e.l - 8) & 15, q = oi - P::ratio0;                            // q = 0..3: the ratios of :156-165
+    const bool is_ratio = q >= 0 && q < 4;
+    int inum = e.K - tasks, iden = e.K;                                           // finish_rate: types with their one task assigned
+    inum = is_ratio ? (q == 0 ? delay_a : (q == 1 ? delay_e : (q == 2 ? job_a : job_e))) : inum;
+    iden = is_ratio ? (q < 2 ? tasks : jobs) : iden;
+    iden = e.l == L_ave2 ? e.M : iden;
+    double num = (double)inum;
+    num = e.l == L_ave1 ? cs1 : num;
+    num = e.l == L_ave2 ? tsum_td : num;
+    const double q1 = num / (double)iden;
     const double ave_fr = bcd<L_ave0>(q1), ave_gr = bcd<L_ave1>(q1), ave_td = bcd<L_ave2>(q1);
     // ---- second pass: squared deviations (math.pow(d, 2), :86-95), population standard deviations
+    const double f0 = (0.0 - ave_fr) * (0.0 - ave_fr), f1 = (1.0 - ave_fr) * (1.0 - ave_fr);
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
-        if (s < e.nslots) {
-            const bool valid = ((e.kB[s] >> 24) & 2u) != 0;
-            const double d1 = frv[s] - ave_fr, d2 = grv[s] - ave_gr;
-            if (on && 16 * s + e.l < e.n8w) { e.rows[16 * s + e.l] = valid ? d1 * d1 : 0.0; e.rows[e.ks + 16 * s + e.l] = valid ? d2 * d2 : 0.0; }
+        if (SLOT_ON(e, s)) {
+            const double q0 = __hiloint2double((int)q0h[s], 0);          // 1.0, or 0.0 for padding (x * 0.0 = 0.0: an exact identity)
+            const double d2 = grv[s] - ave_gr;
+            e.rows[16 * s + e.l] = (in[s] ? f0 : f1) * q0;
+            e.rows[KS + 16 * s + e.l] = (d2 * d2) * q0;
         }
     }
     double d3 = (double)e.tend - ave_td;
@@ -492,26 +555,32 @@ GDEV double g_observe(const GE<V> &e, const GP &p, bool on, bool stats_only, lon
     lds_sync();
     const double cs2 = g_walk<V>(e, on && (e.l == L_sd0 || e.l == L_sd1), e.l == L_sd1 ? 1 : 0);
     lds_sync();
-    double num2 = 0.0, den2 = 1.0;
-    if (e.l == L_sd0 || e.l == L_sd1) { num2 = cs2; den2 = (double)e.K; }
-    if (e.l == L_sd2) { num2 = cs_td; den2 = (double)e.M; }
-    const double q2 = sqrt(num2 / den2);
-    const int oi = (e.l - 8) & 15;
-    double cur = q1;
-    if (oi >= P::ratio0 && oi < P::ratio0 + 4 && e.done) cur = 0.0;               // the ratios are 0 once the episode is over
-    if (e.l == L_sd0 || e.l == L_sd1 || e.l == L_sd2) cur = q2;
-    if (is_so_v<V> && oi == 0) cur = (double)e.M;
+    const double num2 = e.l == L_sd2 ? cs_td : cs2;
+    const double q2 = sqrt(num2 / (double)(e.l == L_sd2 ? e.M : e.K));
+    double cur = (is_ratio && e.done) ? 0.0 : q1;                                 // the ratios are 0 once the episode is over
+    cur = (e.l == L_sd0 || e.l == L_sd1 || e.l == L_sd2) ? q2 : cur;
+    if (is_so_v<V>) cur = oi == 0 ? (double)e.M : cur;
     return cur;
 }
 
+// v(t-1) of the state vector is the observation of the environment as a step finds it; steps that handed no state back did
+// not keep it current (fjsp_kernels.hip obs_refresh).  (Inline like everything else: a call would pin the row state in scratch.)
+template <int V>
+GDEV void g_obs_refresh(GE<V> &e, bool on) {
+    long long tu;
+    const double v = g_observe<V>(e, on, false, &tu);
+    if (on && ((e.l - 8) & 15) < kNObs<V>) e.obs_prev = v;
+    if (on) e.misc &= ~(1u << 24);
+}
+
 // Reward and bookkeeping of step() (SO_FJSSP.py:259-265, MO_FJSSP_discretes.py:232-244) once the observation is out.
-struct MoW { double w0, w1, cn, tn; };      // MO_FJSSP_discretes.py:88 weight vector + normalisers (defaults: d_mo == NULL)
 template <int V>
 GDEV double g_reward(GE<V> &e, bool go, const MoW &mo, long long tard_unproc) {
     const long long delay_new = e.tard_done + tard_unproc;                       // :259
     const long long delta = delay_new - e.delay_sum;
     const int dc = e.completion_last - e.completion;
-    if (go) { e.delay_sum = delay_new; e.completion_last = e.completion; }       // :263
+    e.delay_sum = go ? delay_new : e.delay_sum;                                  // :263
+    e.completion_last = go ? e.completion : e.completion_last;
     double r;
     if (V != FJSP_VARIANT_MO_FJSSP_DISCRETES) r = (double)(-delta);              // :328 (exact integer)
     else {
@@ -519,7 +588,7 @@ GDEV double g_reward(GE<V> &e, bool go, const MoW &mo, long long tard_unproc) {
         if (cn > 0.0 && tn > 0.0) r = (double)dc / cn * w0 + (double)(-delta) / tn * w1;
         else if (w1 == 1.0) r = (double)(-delta);
         else if (w0 == 1.0) r = (double)dc;
-        else { r = 0.0; if (go) e.status |= FJSP_ST_BAD_TASK_RULE; }             // MyError :244
+        else { r = 0.0; e.status |= go ? (uint32_t)FJSP_ST_BAD_TASK_RULE : 0u; }   // MyError :244
     }
     return go ? r : 0.0;
 }
@@ -541,9 +610,10 @@ GDEV void g_emit(GE<V> &e, bool on, double cur, const double *sstate, double *st
 }
 
 // Bind the four rows of a wave to their records and bring the environments in: every load is independent of the
-// others (bounds come from the kernel arguments), one memory round trip.
-template <int V>
-GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds) {
+// others (bounds come from the kernel arguments), one memory round trip.  `between` runs after the loads are out and
+// before they are waited for (the kernels request the gap_ave rows there).
+template <int V, class F>
+GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, int rows_per_env, F &&between) {
     using FO = FixedOffsets;
     const int lane = (int)__lane_id();
     e.l = lane & 15; e.gb = lane & 48;
@@ -556,17 +626,18 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds) {
     const unsigned char *ir = b.inst + (size_t)inst * b.L.i_stride;
     unsigned char *er = b.envs + (size_t)e.env * FO::e_stride_plain((uint32_t)MP, (uint32_t)JP, 64u, true);
     e.ir = ir; e.er = er;
-    e.ks = row_stride(b.kmax);
-    e.rows = reinterpret_cast<double *>(lds) + (size_t)(lane >> 4) * (MP < 2 ? 2 : MP) * e.ks;
+    e.rows = reinterpret_cast<double *>(lds) + (size_t)(lane >> 4) * rows_per_env * KS;
     // ---- issue every load
-    const int4 h = *reinterpret_cast<const int4 *>(ir);
+    const unsigned char *op = ir + b.L.i_op;
+    const uint32_t hw = reinterpret_cast<const uint32_t *>(op + 2048)[e.l];        // machine / job / instance words
+    const int duej = reinterpret_cast<const int32_t *>(op + 2048 + 64)[e.l];
     uint4 A[GS];
     double2 B[GS];
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
         A[s] = make_uint4(0u, 0u, 0u, 0u); B[s] = make_double2(0.0, 0.0);
         if (16 * s + e.l < b.kmax) {
-            const unsigned char *slot = ir + b.L.i_op + s * 512;
+            const unsigned char *slot = op + s * 512;
             A[s] = reinterpret_cast<const uint4 *>(slot)[e.l];
             B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];
         }
@@ -582,8 +653,11 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds) {
     const long long sc = reinterpret_cast<const long long *>(er)[e.l];            // EnvScalars words 0..15
     long long sc2 = 0;
     if (e.l < 2) sc2 = reinterpret_cast<const long long *>(er)[16 + e.l];         // obs_prev[8], [9]
+    // (the slots in use are known from the batch until the instance words arrive: the requests of `between` cover them all)
+    e.nslots = (b.kmax + 15) >> 4;
+    between();
     // ---- consume
-    e.K = h.x; e.M = h.y; e.njobs = h.w;
+    e.K = (int)(bcu<0>(hw) >> 24); e.M = (int)(bcu<1>(hw) >> 24); e.njobs = (int)(bcu<2>(hw) >> 24);
     e.mmask = (1u << e.M) - 1u;
     {
         const int k0 = __builtin_amdgcn_readlane(e.K, 0), k1 = __builtin_amdgcn_readlane(e.K, 16);
@@ -594,11 +668,14 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds) {
     }
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
-        e.kB[s] = A[s].x; e.em[s] = A[s].y; e.due[s] = (int)A[s].z;
+        e.kB[s] = (A[s].x >> 24) & 2u ? A[s].x : 0x000F0000u;      // (no operation type: kind 15, see GE)
+        e.em[s] = A[s].y; e.due[s] = (int)A[s].z;
         e.rsum[s] = B[s].x; e.tsum[s] = B[s].y;
     }
-    e.mcnt = (int)A[0].w;                                   // (slot 0, lane m: operation types machine m can process)
-    e.asgw = asgw; e.jwl = jwl;
+    e.mcnt = (int)(hw & 0xFFu);
+    e.jinfo = (hw >> 8) & 0xFFFFu;
+    e.duej = duej;
+    e.asgw = asgw; e.jwl = e.l < e.njobs ? jwl : 0xFFFFFFFFu;
     e.tend = e.l < e.M ? tend : 0; e.mjob = e.l < e.M ? mjob : -1;
     const int lo = (int)sc, hi = (int)(sc >> 32);
     e.t = bc<0>(lo); e.step_count = bc<0>(hi);
@@ -610,7 +687,6 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds) {
     e.t_arr = bc<7>(lo); e.misc = bcu<7>((uint32_t)hi);
     e.obs_prev = __longlong_as_double(e.l >= 8 ? sc : sc2);
     e.env_seed = b.rng_seed + (uint64_t)e.env * 1000003ULL;
-    g_refresh_jw<V>(e);
 }
 
 template <int V>
@@ -664,68 +740,97 @@ GDEV void g_restart(GE<V> &e, const DevBatch &b, bool on) {
         e.asgw = 0xFFFFFFFFu;                                                   // :304 unprocessed = arrival
         e.obs_prev = o0;
     }
-    g_refresh_jw<V>(e);
 }
 
-// One step() of the rows with go_in.  need_obs: the caller wants the state vector (state_out may still be null: the
-// policy rollout keeps it in registers).  Returns the reward; *k_out / *m_out the chosen pair (-1: none).
-template <int V>
+// One step() of the rows with go_in.  need_obs: the caller wants the state vector.  cr: the gap_ave rows requested for
+// the rows with gap_need (g_cols_issue).  Returns the reward; *k_out / *m_out the chosen pair (-1: none).
+template <int V, int MPC, bool EARLY>
 GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, const MoW &mo, bool need_obs, double *state_out,
-                   int *k_out, int *m_out) {
+                   bool gap_need, const GCols<MPC> &cr, int *k_out, int *m_out) {
     constexpr bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES;
     bool go = go_in;
-    GP p;
-    g_params<V>(e, p);
+    *k_out = -1; *m_out = -1;
+#if defined(FJSP_GABLATE) && FJSP_GABLATE == 1
+    return 0.0;                                                                   // diagnostic: state in / state out only
+#endif
     const bool stale = (e.misc >> 24) & 1u;
-    if (need_obs && wave_any(go && stale)) {
-        // v(t-1) of the state vector is the observation of the environment as this step finds it; steps that handed no
-        // state back did not keep it current (fjsp_kernels.hip obs_refresh)
-        long long tu;
-        const double v = g_observe<V>(e, p, go && stale, false, &tu);
-        if (go && stale && ((e.l - 8) & 15) < kNObs<V>) e.obs_prev = v;
-        if (go && stale) e.misc &= ~(1u << 24);
-    }
+    if (need_obs && wave_any(go && stale)) g_obs_refresh<V>(e, go && stale);
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
-        if (go && a0 >= 18) { e.status |= FJSP_ST_BAD_TASK_RULE; go = false; }   // IndexError
+        e.status |= (go && a0 >= 18) ? (uint32_t)FJSP_ST_BAD_TASK_RULE : 0u;     // IndexError
+        go = go && a0 < 18;
         a1 = a0 % 3; a0 = a0 / 3;
     }
+    g_gather_current<V>(e, wave_any(go && a0 == 2));
     const uint32_t idle = ~e.busy & e.mmask;
-    const int k_sel = g_task_select<V>(e, p, go, a0, idle);
-    go = go && k_sel >= 0;
-    const int ks = go ? k_sel : 0;
-    const uint32_t kb_sel = greadu(pick_slot(e.kB, ks >> 4), ks & 15, e.gb);
-    const uint32_t em_sel = greadu(pick_slot(e.em, ks >> 4), ks & 15, e.gb);
-    const int due_sel = gread(pick_slot(e.due, ks >> 4), ks & 15, e.gb);
+    const int r_sel = g_task_select<V>(e, go, a0, idle);
+    if (wave_any(gap_need)) {         // (after task_select: the rows requested at the start of the step have had time to arrive)
+        if (EARLY) g_gap_rows<V, MPC>(e, gap_need, cr);
+        else g_gap_rows_late<V, MPC>(e, b, gap_need);
+        lds_sync();
+    }
+#if defined(FJSP_GABLATE) && FJSP_GABLATE == 2
+    e.rng_calls += (uint32_t)r_sel; return 0.0;                                  // diagnostic: stop after task_select
+#endif
+    go = go && r_sel >= 0;
+    const int rs = go ? r_sel : 0;
+    // the job's current operation type and its elig | fmask: from the job's lane
+    const int k_sel = gread((int)(e.jinfo & 0xFFu) + (int)(e.jwl & 0xFFu), rs, e.gb);
+    const uint32_t em_sel = greadu(e.emc, rs, e.gb);
     int pm = 0;
-    const int m_sel = g_machine_select<V>(e, b, go, a1, ks, em_sel, idle, &pm);
-    *k_out = k_sel; *m_out = m_sel;
+    const int m_sel = g_machine_select<V>(e, b, go, a1, k_sel, em_sel, idle, gap_need, &pm);
+    *k_out = go ? k_sel : -1; *m_out = m_sel;
+#if defined(FJSP_GABLATE) && FJSP_GABLATE == 3
+    e.rng_calls += (uint32_t)(m_sel + pm); return 0.0;                           // diagnostic: stop after machine_select
+#endif
     go = go && m_sel >= 0;
-    g_dispatch_advance<V>(e, go, ks, m_sel, pm, kb_sel, due_sel);
-    if (go) e.step_count++;                                                      // :252
-    g_params<V>(e, p);
+    g_dispatch_advance<V>(e, go, rs, k_sel, m_sel, pm);
+#if defined(FJSP_GABLATE) && FJSP_GABLATE == 4
+    return 0.0;                                                                   // diagnostic: stop after dispatch_and_advance
+#endif
+    e.step_count += go ? 1 : 0;                                                  // :252
     long long tard_unproc = 0;
-    const double cur = g_observe<V>(e, p, go, !need_obs, &tard_unproc);       // :256
+#if defined(FJSP_GABLATE) && FJSP_GABLATE == 5
+    const double cur = g_observe<V>(e, go, true, &tard_unproc);               // diagnostic: statistics only, no observation
+#else
+    const double cur = g_observe<V>(e, go, !need_obs, &tard_unproc);          // :256
+#endif
     if (need_obs) g_emit<V>(e, go, cur, reinterpret_cast<const double *>(e.ir + b.L.i_ss), state_out);
-    else if (go) e.misc |= 1u << 24;
+    else e.misc |= go ? 1u << 24 : 0u;
     return g_reward<V>(e, go, mo, tard_unproc);
+}
+
+// does the rule pair of a row rank its candidate machines by Machine.gap_ave (SO_FJSSP.py:313-317 rule 4,
+// MO_FJSSP_discretes.py:218-222 rule 2 of the flat action's pair)
+template <int V>
+GDEV bool rule_wants_gap_ave(uint32_t araw) {
+    if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES) return (araw & 0xFFu) < 18u && (araw & 0xFFu) % 3u == 1u;
+    return (araw >> 8) == 3u;
 }
 
 // ------------------------------------------------------------------------ kernels
 // One step of every environment of a group batch (fjsp_kernels.hip step_kernel for the same batch gives the same results)
-template <int V>
-__global__ __launch_bounds__(64) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
+// EARLY: request the gap_ave rows together with the state (small batches: a wave is alone on its SIMD and nothing else hides
+// the memory round trip); otherwise they are fetched where they are used and the kernel keeps to 128 registers
+template <int V, int MPC, bool EARLY>
+__global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
                                                    double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     GE<V> e;
     const int wave_id = (int)blockIdx.x;
     // the action pair of the row's environment (2-byte aligned: checked by the host entry points)
-    const int env0 = min(wave_id * 4 + (int)(__lane_id() >> 4), b.N - 1);
+    const int env_raw = wave_id * 4 + (int)(__lane_id() >> 4);
+    const int env0 = min(env_raw, b.N - 1);
     const uint32_t araw = reinterpret_cast<const uint16_t *>(actions)[env0];
     MoW mw = {0.0, 1.0, 0.0, 0.0};
     if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES && mo) {
         const double2 m01 = *reinterpret_cast<const double2 *>(mo + (size_t)env0 * 4), m23 = *reinterpret_cast<const double2 *>(mo + (size_t)env0 * 4 + 2);
         mw.w0 = m01.x; mw.w1 = m01.y; mw.cn = m23.x; mw.tn = m23.y;
     }
-    g_open<V>(e, b, wave_id, g_lds);
+    GCols<MPC> cr;
+    bool gap_need = false;
+    g_open<V>(e, b, wave_id, g_lds, MPC, [&]() __attribute__((always_inline)) {
+        gap_need = env_raw < b.N && rule_wants_gap_ave<V>(araw);
+        if (EARLY) g_cols_issue<V, MPC>(e, b, gap_need, cr);
+    });
     const int a0 = (int)(araw & 0xFFu), a1 = (int)(araw >> 8);
     bool go = e.live;
     if (wave_any(go && e.done != 0)) {
@@ -737,7 +842,7 @@ __global__ __launch_bounds__(64) void gstep_kernel(DevBatch b, const uint8_t *ac
         }
     }
     int k_sel = -1, m_sel = -1;
-    const double reward = g_step<V>(e, b, go, a0, a1, mw, state_out != nullptr, state_out, &k_sel, &m_sel);
+    const double reward = g_step<V, MPC, EARLY>(e, b, go, a0, a1, mw, state_out != nullptr, state_out, gap_need && go, cr, &k_sel, &m_sel);
     if (e.live && e.l == 0) {
         if (reward_out) reward_out[e.env] = reward;
         if (done_out) done_out[e.env] = (uint8_t)e.done;
@@ -748,12 +853,12 @@ __global__ __launch_bounds__(64) void gstep_kernel(DevBatch b, const uint8_t *ac
 
 // T fused steps per launch with the actions given (rule sweeps): the environments live in registers for the whole
 // launch.  Same outputs as fjsp_kernels.hip rollout_kernel.
-template <int V>
-__global__ __launch_bounds__(64) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
+template <int V, int MPC, bool EARLY>
+__global__ __launch_bounds__(64, EARLY ? 1 : 3) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
                                                       double *reward_out, double *state_last) {
     GE<V> e;
     const int wave_id = (int)blockIdx.x;
-    g_open<V>(e, b, wave_id, g_lds);
+    g_open<V>(e, b, wave_id, g_lds, MPC, []() {});
     MoW mw = {0.0, 1.0, 0.0, 0.0};
     if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES && mo) {
         mw.w0 = mo[(size_t)e.env * 4]; mw.w1 = mo[(size_t)e.env * 4 + 1]; mw.cn = mo[(size_t)e.env * 4 + 2]; mw.tn = mo[(size_t)e.env * 4 + 3];
@@ -769,9 +874,12 @@ __global__ __launch_bounds__(64) void grollout_kernel(DevBatch b, const uint8_t 
             continue;
         }
         const uint32_t araw = reinterpret_cast<const uint16_t *>(actions)[o];
+        const bool gap_need = go && rule_wants_gap_ave<V>(araw);
+        GCols<MPC> cr;
+        if (EARLY) g_cols_issue<V, MPC>(e, b, gap_need, cr);
         int k_sel = -1, m_sel = -1;
-        const double reward = g_step<V>(e, b, go, (int)(araw & 0xFFu), (int)(araw >> 8), mw, state_last != nullptr,
-                                        state_last, &k_sel, &m_sel);
+        const double reward = g_step<V, MPC, EARLY>(e, b, go, (int)(araw & 0xFFu), (int)(araw >> 8), mw, state_last != nullptr, state_last,
+                                             gap_need, cr, &k_sel, &m_sel);
         if (e.live && e.l == 0) {
             if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }
             if (reward_out) reward_out[o] = reward;
@@ -783,36 +891,50 @@ __global__ __launch_bounds__(64) void grollout_kernel(DevBatch b, const uint8_t 
 }  // namespace grp
 
 // ------------------------------------------------------------------ host launchers
-template <class K>
-static inline void grp_allow_lds(K kernel, size_t lds) {
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// Batches that leave the chip's SIMDs with at most two waves each (4 environments per wave, 1 024 SIMDs) run the variant that
+// requests Machine.gap_ave's rows ahead of time; larger ones the register-lean one.  FJSP_GROUP_EARLY=0/1 overrides (A/B runs).
+static bool group_early(const DevBatch &b) {
+    static const int forced = [] { const char *v = getenv("FJSP_GROUP_EARLY"); return v ? atoi(v) : -1; }();
+    return forced >= 0 ? forced != 0 : b.N <= 8192;
 }
-
+template <int V>
+static int launch_step_group_v(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
+                               uint8_t *done, int16_t *trace_km, hipStream_t st) {
+    const dim3 grid((unsigned)((b.N + 3) / 4));
+    const bool early = group_early(b);
+#define FJSP_GSTEP(MPC, E) hipLaunchKernelGGL((grp::gstep_kernel<V, MPC, E>), grid, dim3(64), grp::group_lds_bytes<MPC>(), st, b, actions, mo, autoreset, state, reward, done, trace_km)
+    if (b.MP <= 5) { if (early) FJSP_GSTEP(5, true); else FJSP_GSTEP(5, false); }
+    else { if (early) FJSP_GSTEP(8, true); else FJSP_GSTEP(8, false); }
+#undef FJSP_GSTEP
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_step_group(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                       uint8_t *done, int16_t *trace_km, hipStream_t st) {
     if (!b.grp) return -1;
-    const size_t lds = grp::group_lds_bytes(b.kmax, b.MP);
-    const dim3 grid((unsigned)((b.N + 3) / 4));
-    if (b.variant == FJSP_VARIANT_SO_FJSSP)
-        hipLaunchKernelGGL((grp::gstep_kernel<FJSP_VARIANT_SO_FJSSP>), grid, dim3(64), lds, st, b, actions, mo, autoreset, state, reward, done, trace_km);
-    else if (b.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES)
-        hipLaunchKernelGGL((grp::gstep_kernel<FJSP_VARIANT_MO_FJSSP_DISCRETES>), grid, dim3(64), lds, st, b, actions, mo, autoreset, state, reward, done, trace_km);
-    else return -1;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (b.variant == FJSP_VARIANT_SO_FJSSP) return launch_step_group_v<FJSP_VARIANT_SO_FJSSP>(b, actions, mo, autoreset, state, reward, done, trace_km, st);
+    if (b.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES)
+        return launch_step_group_v<FJSP_VARIANT_MO_FJSSP_DISCRETES>(b, actions, mo, autoreset, state, reward, done, trace_km, st);
+    return -1;
 }
 
+template <int V>
+static int launch_rollout_group_v(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
+                                  double *state_last, hipStream_t st) {
+    const dim3 grid((unsigned)((b.N + 3) / 4));
+    const bool early = group_early(b);
+#define FJSP_GROLL(MPC, E) hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64), grp::group_lds_bytes<MPC>(), st, b, actions, mo, T, trace_km, reward, state_last)
+    if (b.MP <= 5) { if (early) FJSP_GROLL(5, true); else FJSP_GROLL(5, false); }
+    else { if (early) FJSP_GROLL(8, true); else FJSP_GROLL(8, false); }
+#undef FJSP_GROLL
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_rollout_group(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                          double *state_last, hipStream_t st) {
     if (!b.grp) return -1;
-    const size_t lds = grp::group_lds_bytes(b.kmax, b.MP);
-    const dim3 grid((unsigned)((b.N + 3) / 4));
-    if (b.variant == FJSP_VARIANT_SO_FJSSP)
-        hipLaunchKernelGGL((grp::grollout_kernel<FJSP_VARIANT_SO_FJSSP>), grid, dim3(64), lds, st, b, actions, mo, T, trace_km, reward, state_last);
-    else if (b.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES)
-        hipLaunchKernelGGL((grp::grollout_kernel<FJSP_VARIANT_MO_FJSSP_DISCRETES>), grid, dim3(64), lds, st, b, actions, mo, T, trace_km, reward, state_last);
-    else return -1;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (b.variant == FJSP_VARIANT_SO_FJSSP) return launch_rollout_group_v<FJSP_VARIANT_SO_FJSSP>(b, actions, mo, T, trace_km, reward, state_last, st);
+    if (b.variant == FJSP_VARIANT_MO_FJSSP_DISCRETES)
+        return launch_rollout_group_v<FJSP_VARIANT_MO_FJSSP_DISCRETES>(b, actions, mo, T, trace_km, reward, state_last, st);
+    return -1;
 }
 
 }  // namespace fjsp
