@@ -63,6 +63,7 @@ SIGNATURES = {
     "fjsp_env_energy": (C.c_int, [_vp, _vp, _vp]),
     "fjsp_env_fluid_tables": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "fjsp_env_step_bytes": (_i64, [_vp]),
+    "fjsp_env_kernel_family": (_i32, [_vp]),
     "fjsp_env_set_lp_threads": (C.c_int, [_vp, _i32]),
     "fjsp_env_lp_solves": (_i64, [_vp]),
     "fjsp_pyset_and_order": (C.c_int, [C.c_uint32, _vp, _i32, _i32, _vp]),

@@ -111,6 +111,8 @@ class EnvBatch(object):
         self.rng_seed = int(rng_seed)
         self.state_size = self._lib.fjsp_env_state_size(self._h)
         self.step_bytes = int(self._lib.fjsp_env_step_bytes(self._h))
+        # 1: stepped by the 16-lane-row kernels (csrc/fjsp_group.hip), 0: one wavefront per environment
+        self.kernel_family = int(self._lib.fjsp_env_kernel_family(self._h))
         f64 = dict(dtype=torch.float64, device=self.device)
         self.state = torch.zeros(self.N, self.state_size, **f64)
         self.reward = torch.zeros(self.N, **f64)

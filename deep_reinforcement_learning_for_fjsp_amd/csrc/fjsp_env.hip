@@ -643,6 +643,7 @@ int fjsp_env_num_envs(const fjsp_env *e) { return e ? e->b.N : 0; }
 int fjsp_env_state_size(const fjsp_env *e) { return e ? e->b.state_size : 0; }
 int fjsp_env_device(const fjsp_env *e) { return e ? e->device : -1; }
 int64_t fjsp_env_step_bytes(const fjsp_env *e) { return e ? e->step_bytes : 0; }
+int fjsp_env_kernel_family(const fjsp_env *e) { return e ? e->b.grp : 0; }
 int64_t fjsp_env_lp_solves(const fjsp_env *e) { return e ? e->lp_solves : 0; }
 int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads) {
     if (!e || n_threads < 0) { set_error("fjsp_env_set_lp_threads: bad arguments"); return FJSP_E_ARG; }

@@ -59,6 +59,22 @@ constexpr uint32_t kSeqNone = kNoSeq << 8;      // state words at or above it: t
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
+// -DFJSP_GSTAMPS builds a DIAGNOSTIC library (never shipped, never benchmarked): lane 0 of every wave adds the s_memtime
+// delta of each phase of a step to a global table (tools/stamp_group.py)
+#ifdef FJSP_GSTAMPS
+__device__ unsigned long long fjsp_gstamp_acc[16];
+__device__ unsigned long long g_stamp_t0;
+#define GSTAMP_DECL unsigned long long gst[14]; unsigned long long gst_t0
+#define GSTAMP_BEGIN() do { for (int _i = 0; _i < 14; ++_i) gst[_i] = 0; gst_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define GSTAMP(slot) do { const unsigned long long _t1 = __builtin_amdgcn_s_memtime(); gst[slot] += _t1 - gst_t0; gst_t0 = _t1; } while (0)
+#define GSTAMP_FLUSH() do { if (__lane_id() == 0) { for (int _i = 0; _i < 14; ++_i) atomicAdd(&fjsp_gstamp_acc[_i], gst[_i]); atomicAdd(&fjsp_gstamp_acc[15], 1ull); } } while (0)
+#else
+#define GSTAMP_DECL
+#define GSTAMP_BEGIN()
+#define GSTAMP(slot)
+#define GSTAMP_FLUSH()
+#endif
+
 // ---- row primitives
 template <int N>
 GDEV int bc(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, false); }       // row_newbcast:N (every lane is read from: `old` is never used)
@@ -744,9 +760,16 @@ GDEV void g_restart(GE<V> &e, const DevBatch &b, bool on) {
 
 // One step() of the rows with go_in.  need_obs: the caller wants the state vector.  cr: the gap_ave rows requested for
 // the rows with gap_need (g_cols_issue).  Returns the reward; *k_out / *m_out the chosen pair (-1: none).
+#ifdef FJSP_GSTAMPS
+#define GSTAMP_PARAM , unsigned long long (&gst)[14], unsigned long long &gst_t0
+#define GSTAMP_ARG , gst, gst_t0
+#else
+#define GSTAMP_PARAM
+#define GSTAMP_ARG
+#endif
 template <int V, int MPC, bool EARLY>
 GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, const MoW &mo, bool need_obs, double *state_out,
-                   bool gap_need, const GCols<MPC> &cr, int *k_out, int *m_out) {
+                   bool gap_need, const GCols<MPC> &cr, int *k_out, int *m_out GSTAMP_PARAM) {
     constexpr bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES;
     bool go = go_in;
     *k_out = -1; *m_out = -1;
@@ -761,8 +784,10 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
         a1 = a0 % 3; a0 = a0 / 3;
     }
     g_gather_current<V>(e, wave_any(go && a0 == 2));
+    GSTAMP(2);
     const uint32_t idle = ~e.busy & e.mmask;
     const int r_sel = g_task_select<V>(e, go, a0, idle);
+    GSTAMP(3);
     if (wave_any(gap_need)) {         // (after task_select: the rows requested at the start of the step have had time to arrive)
         if (EARLY) g_gap_rows<V, MPC>(e, gap_need, cr);
         else g_gap_rows_late<V, MPC>(e, b, gap_need);
@@ -773,6 +798,7 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
 #endif
     go = go && r_sel >= 0;
     const int rs = go ? r_sel : 0;
+    GSTAMP(4);
     // the job's current operation type and its elig | fmask: from the job's lane
     const int k_sel = gread((int)(e.jinfo & 0xFFu) + (int)(e.jwl & 0xFFu), rs, e.gb);
     const uint32_t em_sel = greadu(e.emc, rs, e.gb);
@@ -783,7 +809,9 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
     e.rng_calls += (uint32_t)(m_sel + pm); return 0.0;                           // diagnostic: stop after machine_select
 #endif
     go = go && m_sel >= 0;
+    GSTAMP(5);
     g_dispatch_advance<V>(e, go, rs, k_sel, m_sel, pm);
+    GSTAMP(6);
 #if defined(FJSP_GABLATE) && FJSP_GABLATE == 4
     return 0.0;                                                                   // diagnostic: stop after dispatch_and_advance
 #endif
@@ -794,6 +822,7 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
 #else
     const double cur = g_observe<V>(e, go, !need_obs, &tard_unproc);          // :256
 #endif
+    GSTAMP(7);
     if (need_obs) g_emit<V>(e, go, cur, reinterpret_cast<const double *>(e.ir + b.L.i_ss), state_out);
     else e.misc |= go ? 1u << 24 : 0u;
     return g_reward<V>(e, go, mo, tard_unproc);
@@ -815,6 +844,8 @@ template <int V, int MPC, bool EARLY>
 __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
                                                    double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     GE<V> e;
+    GSTAMP_DECL;
+    GSTAMP_BEGIN();
     const int wave_id = (int)blockIdx.x;
     // the action pair of the row's environment (2-byte aligned: checked by the host entry points)
     const int env_raw = wave_id * 4 + (int)(__lane_id() >> 4);
@@ -833,6 +864,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, co
     });
     const int a0 = (int)(araw & 0xFFu), a1 = (int)(araw >> 8);
     bool go = e.live;
+    GSTAMP(0);
     if (wave_any(go && e.done != 0)) {
         const bool was_done = go && e.done != 0;
         if (autoreset == 1) g_restart<V>(e, b, was_done);
@@ -842,21 +874,26 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, co
         }
     }
     int k_sel = -1, m_sel = -1;
-    const double reward = g_step<V, MPC, EARLY>(e, b, go, a0, a1, mw, state_out != nullptr, state_out, gap_need && go, cr, &k_sel, &m_sel);
+    GSTAMP(1);
+    const double reward = g_step<V, MPC, EARLY>(e, b, go, a0, a1, mw, state_out != nullptr, state_out, gap_need && go, cr, &k_sel, &m_sel GSTAMP_ARG);
     if (e.live && e.l == 0) {
         if (reward_out) reward_out[e.env] = reward;
         if (done_out) done_out[e.env] = (uint8_t)e.done;
         if (trace_km) { trace_km[(size_t)e.env * 2] = (int16_t)k_sel; trace_km[(size_t)e.env * 2 + 1] = (int16_t)m_sel; }
     }
     g_store<V>(e, b);
+    GSTAMP(8);
+    GSTAMP_FLUSH();
 }
 
 // T fused steps per launch with the actions given (rule sweeps): the environments live in registers for the whole
 // launch.  Same outputs as fjsp_kernels.hip rollout_kernel.
 template <int V, int MPC, bool EARLY>
-__global__ __launch_bounds__(64, EARLY ? 1 : 3) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
+__global__ __launch_bounds__(64, EARLY ? 1 : 2) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
                                                       double *reward_out, double *state_last) {
     GE<V> e;
+    GSTAMP_DECL;
+    GSTAMP_BEGIN();
     const int wave_id = (int)blockIdx.x;
     g_open<V>(e, b, wave_id, g_lds, MPC, []() {});
     MoW mw = {0.0, 1.0, 0.0, 0.0};
@@ -879,7 +916,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 3) void grollout_kernel(DevBatch b,
         if (EARLY) g_cols_issue<V, MPC>(e, b, gap_need, cr);
         int k_sel = -1, m_sel = -1;
         const double reward = g_step<V, MPC, EARLY>(e, b, go, (int)(araw & 0xFFu), (int)(araw >> 8), mw, state_last != nullptr, state_last,
-                                             gap_need, cr, &k_sel, &m_sel);
+                                             gap_need, cr, &k_sel, &m_sel GSTAMP_ARG);
         if (e.live && e.l == 0) {
             if (trace_km) { trace_km[o * 2] = (int16_t)k_sel; trace_km[o * 2 + 1] = (int16_t)m_sel; }
             if (reward_out) reward_out[o] = reward;
@@ -889,6 +926,17 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 3) void grollout_kernel(DevBatch b,
 }
 
 }  // namespace grp
+
+#ifdef FJSP_GSTAMPS
+extern "C" int fjsp_debug_read_gstamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(grp::fjsp_gstamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(grp::fjsp_gstamp_acc), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------ host launchers
 // Batches that leave the chip's SIMDs with at most two waves each (4 environments per wave, 1 024 SIMDs) run the variant that

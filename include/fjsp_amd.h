@@ -237,6 +237,11 @@ int fjsp_env_fluid_tables(fjsp_env *e, int32_t i, double *h_rate, double *h_arr,
 int fjsp_pyset_and_order(uint32_t idle_mask, const int32_t *machines, int32_t n, int32_t ascending, int32_t *out);
 /* HBM bytes the step kernel reads+writes per env-step (algorithmic). */
 int64_t fjsp_env_step_bytes(const fjsp_env *e);
+/* Which kernel family steps this batch: 0 = one wavefront per environment (csrc/fjsp_kernels.hip: every variant and
+ * shape), 1 = one 16-lane row per environment (csrc/fjsp_group.hip: SO_FJSSP / SO_DFJSP / MO_FJSSP_discretes batches of
+ * one job per kind, one order, <= 64 operation types, <= 8 machines, <= 15 jobs -- the reference's 10x5 and Brandimarte
+ * shapes).  Same results either way; the environment variable FJSP_STEP_IMPL=wave at create time forces 0. */
+int fjsp_env_kernel_family(const fjsp_env *e);
 /* Order arrivals (SO_FJSSP.py:218-231) re-solve the fluid LP on the host, one LP per arriving env, spread
  * over n_threads host threads (0 = default: min(host cores, 16)).  fjsp_env_lp_solves: LPs solved so far. */
 int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads);

@@ -456,13 +456,16 @@ def test_mo_dfjsp_full_size_batch_against_oracle_and_invariants(torch_gpu):
         assert fin["energy_consumption"][e] == want["energy"] and fin["completion_time"][e] == want["completion_time"], e
 
 
-@pytest.mark.parametrize("shape", ["small", "big", "jobs", "long"])
+@pytest.mark.parametrize("shape", ["small", "big", "jobs", "long", "rows"])
 @pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
 def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     """Beyond the committed reference traces: freshly generated instances of mixed shape -- "small": 96 x (1-6
     kinds, 1-4 stages, 1-12 machines, 1-4 jobs per kind), also shops with more machines than operation types;
     "big": 24 x (8-24 kinds, 3-8 stages -> up to 192 operation types in one batch, i.e. the 2- and 4-chunk
-    kernels, 8-32 machines, 1-3 jobs per kind); "jobs": 32 x (1-4 kinds with up to 60 jobs each) -- 1-3 orders where the variant has arrivals, dense breakdown
+    kernels, 8-32 machines, 1-3 jobs per kind); "jobs": 32 x (1-4 kinds with up to 60 jobs each); "rows": 50 x (1-15 kinds of ONE
+    job, at most 64 operation types and 8 machines, one order: the shapes the 16-lane-row kernels of fjsp_group.hip take for
+    SO_FJSSP / SO_DFJSP / MO_FJSSP_discretes -- operation counts on both sides of 16 / 32 / 48, a last wave that is not full,
+    clocks beyond 2^16) -- 1-3 orders where the variant has arrivals, dense breakdown
     windows for the dynamic variant, random actions over the variant's whole action space, HIP kernels vs the C
     oracle (which is pinned to the reference on 2 921 episodes): choices, rewards, clocks and totals bit for bit,
     states up to the pow() entries."""
@@ -470,18 +473,22 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     from deep_reinforcement_learning_for_fjsp_amd import instances as fi
     from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch
     big = shape == "big"
-    NI = {"small": 96, "big": 24, "jobs": 32, "long": 48}[shape]           # instances; they sit at an offset inside the set
+    NI = {"small": 96, "big": 24, "jobs": 32, "long": 48, "rows": 50}[shape]           # instances; they sit at an offset inside the set
     OFF = 2
     N = NI + NI // 4                                           # environments: the last quarter shares instances
     fuzz = int(os.environ.get("FJSP_FUZZ_SEED", "0"))          # tools/fuzz_parity.sh sweeps this
-    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70, "long": 90}[shape] + 1000 * fuzz)
+    rs = np.random.RandomState(1000 + variant + {"small": 0, "big": 50, "jobs": 70, "long": 90, "rows": 110}[shape] + 1000 * fuzz)
     s = fi.InstanceSet(OFF + NI)
-    multi = variant in (0, 4, 5)
+    multi = variant in (0, 4, 5) and shape != "rows"
     for i in range(OFF, OFF + NI):
         pmin, pmax = 1, int(rs.randint(2, 60))
         if shape == "long":      # one job per kind, processing times near the u16 limit: clocks beyond 2^22
             R = int(rs.randint(20, 41)); Jlo = int(rs.randint(3, 6)); M = int(rs.randint(2, 5)); nmax = 1
             pmin, pmax = 30000, 65535
+        elif shape == "rows":      # one job per kind, <= 15 kinds, <= 64 operation types, <= 8 machines
+            R = int(rs.randint(1, 16)); Jlo = int(rs.randint(1, max(2, min(6, 64 // R)))); M = int(rs.randint(1, 9)); nmax = 1
+            if rs.rand() < 0.25:
+                pmin, pmax = 2000, 65535
         elif shape == "jobs":      # few kinds, many jobs per kind (list positions, FIFO order, several job-table chunks)
             R = int(rs.randint(1, 5)); Jlo = int(rs.randint(2, 5)); M = int(rs.randint(2, 9)); nmax = int(rs.randint(20, 61))
         elif big:
@@ -491,7 +498,7 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
         prm = fi.GenParams(R_min=R, R_max=R, J_min=Jlo, J_max=Jlo + int(rs.randint(0, 2)), M=M, p_min=pmin, p_max=pmax,
                            N_min=1, N_max=nmax, S=int(rs.randint(1, 4)) if multi else 1,
                            DDT=float(rs.choice([0.5, 1.0, 1.5])), t_si_min=20.0, t_si_max=80.0)
-        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000, "long": 37000}[shape] + 1000003 * fuzz
+        seed = 50000 * (variant + 1) + i + {"small": 0, "big": 25000, "jobs": 12000, "long": 37000, "rows": 44000}[shape] + 1000003 * fuzz
         s.generate(i, seed, prm)
         while variant in (4, 5) and not (s.arrays(i).p > 0).any(axis=0).all():  # the reference divides by zero there
             seed += 7919
@@ -519,6 +526,8 @@ def test_randomised_differential_vs_oracle(torch_gpu, variant, shape):
     else:
         mo_rows = None
     mo = None if mo_rows is None else torch.tensor(mo_rows, dtype=torch.float64).cuda()
+    if shape == "rows":      # (SO_FJSSP, SO_DFJSP, MO_FJSSP_discretes: the row kernels; the other variants keep the wave kernels)
+        assert b.kernel_family == (1 if variant in (0, 2, 5) else 0)
     st0 = b.reset().cpu().numpy()
     S = b.state_size
     rewards = np.zeros((T, N)); states = np.zeros((T, N, S))
