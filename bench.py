@@ -130,9 +130,11 @@ def main():
 
     step_ctr = [args.warmup]
     regions = []
+    local_dts = []
     total_t = 0.0
     while len(regions) < 25 or (total_t < 0.05 and len(regions) < 2000):
         dt, ev_ms = timed_region(args.steps)
+        local_dts.append(dt)
         if world > 1:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -140,6 +142,7 @@ def main():
         regions.append((dt, ev_ms))
         total_t += dt
     regions.sort()
+    elapsed_local = sorted(local_dts)[len(local_dts) // 2]       # this rank's own median region (before the max over ranks)
     elapsed, _ = regions[len(regions) // 2]
     region_ms = sorted(r[1] for r in regions)[len(regions) // 2]
     status = env.read()["status"]
@@ -183,7 +186,7 @@ def main():
         # figure says nothing about it.  Its bound is instruction issue: instructions per wave-step (rocprofv3 PMC of
         # this tree, profiles/traffic_step_kernel.json "fused_insts_per_wave_step") x wave-steps / (1024 SIMDs x
         # 2.4 GHz, one instruction per cycle and SIMD).
-        fused = {"kernel": "rollout_kernel", "env_steps_per_launch": steps_per_rollout,
+        fused = {"kernel": "grollout_kernel" if env2.kernel_family == 1 else "rollout_kernel", "env_steps_per_launch": steps_per_rollout,
                  "env_steps_per_s_no_state": steps_per_rollout / (tot2 / reps * 1e-3),
                  "ms_per_launch": tot / reps, "env_steps_per_s": steps_per_rollout / (tot / reps * 1e-3),
                  "bytes_per_env_episode": None, "issue_roofline": None}
@@ -230,6 +233,27 @@ def main():
         cpu_mt = {"value": done_steps / dt, "unit": "env-steps/s", "cores": len(shards), "kind": "port",
                   "sample": "the same %d oracle environments spread over %d host threads (fjo_play_many, 8 episodes per C call) for %.1f s" % (n_s, n_thr, dt)}
 
+    # ---- multi-rank evidence: how many ranks the process group really has, and each rank's own rate (stragglers) ----
+    ranks_seen, per_rank_value = 1, None
+    my_value = N * args.steps / elapsed_local
+    if world > 1:
+        dev = "cuda" if backend == "nccl" else "cpu"
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)                                   # (RCCL over xGMI with the nccl backend)
+        ranks_seen = int(one.item())
+        mine = torch.tensor([my_value], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_value = [float(g.item()) for g in gathered]
+    else:
+        per_rank_value = [my_value]
+
+    # the kernel that steps this batch: 16-lane-row family (csrc/fjsp_group.hip; its variant that requests gap_ave's rows ahead
+    # of time for batches of at most 8192 envs) or one wavefront per environment (csrc/fjsp_kernels.hip)
+    if env.kernel_family == 1:
+        step_kernel_name = "grp::gstep_kernel<0, 5, %s>" % ("true" if N <= 8192 and os.environ.get("FJSP_GROUP_EARLY") != "0" else "false")
+    else:
+        step_kernel_name = "step_kernel<1, 0, true>"
     if rank == 0:
         total_steps = N * world * args.steps
         # average launch duration = HIP events bracketing the K timed launches on the launch stream / K
@@ -263,6 +287,8 @@ def main():
             "value": total_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "per_rank_value": per_rank_value,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -274,13 +300,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d parallel SO_FJSSP 10x5 generated instances per GPU "
-                                   "(seeds 1000+i), random policy, per-step HIP kernel (step_kernel<KC=1, V=SO_FJSSP>) with autoreset, "
-                                   "one launch = one env step of every env" % N,
+                                   "(seeds 1000+i), random policy, per-step HIP kernel (%s) with autoreset, "
+                                   "one launch = one env step of every env" % (N, step_kernel_name),
                        "envs_per_gpu": N, "mean_ops_per_instance": float(K.mean()), "sharding": "env id range per rank, no collective",
                        "host_prep_s": round(t_prep, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "step_kernel<1, 0, true>", "bytes_per_env_step": env.step_bytes,
+                         "kernel": step_kernel_name, "bytes_per_env_step": env.step_bytes,
                          "bytes_per_launch": bytes_per_launch, "launch_us_hip_events": region_us,
                          "launch_us_per_launch_events": kern_us},
             "cpu_baseline": cpu,

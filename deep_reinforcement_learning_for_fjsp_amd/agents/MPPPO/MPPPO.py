@@ -142,6 +142,11 @@ class PPOLearner(object):
         adam = dict(lr=self.hp["learning_rate"], eps=1e-4, fused=fused, capturable=fused)   # capturable: step count on the device
         self.actor_optimizer = optim.Adam(self.actor_new.parameters(), **adam)
         self.critic_optimizer = optim.Adam(self.critic.parameters(), **adam)
+        # which trainer owns the optimiser state -- "fused" (agents/fused_mlp.py, its own Adam moments) or "eager" (the torch
+        # optimisers above) -- is decided ONCE, at the first learn(), from the smallest sample count over the ranks, and
+        # never changes: a learner that switched per call would alternate between two sets of Adam moments, and ranks that
+        # decided from their own shard could take different paths and drift apart
+        self._path = None
         self.graph_learn = False         # replay the learning round from a HIP graph once its sample count repeats
         if self.device.type == "cuda":
             self._fused_nets()           # re-homes the parameters into flat buffers NOW: before any graph captures their addresses
@@ -180,7 +185,11 @@ class PPOLearner(object):
             vmask = torch.ones(idx.shape[0], dtype=torch.bool, device=states.device)
         m = vmask.to(states.dtype)
         # big GPU batches (rows of finished environments already dropped): the fused trainer (agents/fused_mlp.py)
-        self._use_fused = self.fused_learn and states.is_cuda and states.shape[0] >= (1 << 15) and self._fused_nets() is not None
+        if self._path is None:
+            n_min = fdist.all_reduce_scalar_min(torch.tensor(float(states.shape[0]), device=states.device))
+            want = self.fused_learn and states.is_cuda and self._fused_nets() is not None
+            self._path = "fused" if (want and float(n_min) >= float(1 << 15)) else "eager"
+        self._use_fused = self._path == "fused"
         if self.graph_learn and states.is_cuda and not fdist.is_distributed():
             return self._learn_graphed(states, actions, old_log_prob, returns, m)
         count = fdist.all_reduce_scalar_sum(m.sum())          # global number of samples

@@ -41,6 +41,28 @@ struct ObsPos {
 
 #define DPP(v, ctrl, ident) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), 0xF, 0xF, false)
 
+// Sum of a value over the 16 lanes of a DPP row, the result in every lane of the row: four butterfly steps (quad_perm,
+// quad_perm, row_half_mirror, row_mirror).  Floating-point addition is commutative, so every lane ends with the bits of ONE
+// fixed tree -- ((l0 + l1) + (l2 + l3)) per quad, (quad + quad) per half, half + half -- whatever lane pairing a step uses.
+// f64 has no DPP add: each step moves the two halves with v_mov_b32_dpp.
+__device__ __forceinline__ double row_tree_sum_f64(double v) {
+#define FJSP_DPP64(x, ctrl) __hiloint2double(DPP(__double2hiint(x), (ctrl), 0), DPP(__double2loint(x), (ctrl), 0))
+    v = v + FJSP_DPP64(v, 0xB1);
+    v = v + FJSP_DPP64(v, 0x4E);
+    v = v + FJSP_DPP64(v, 0x141);
+    v = v + FJSP_DPP64(v, 0x140);
+#undef FJSP_DPP64
+    return v;
+}
+// THE SUM OF SQUARED DEVIATIONS behind the observation's three population standard deviations (SO_FJSSP.py:86-95) is the
+// one place where the kernels do not add in the reference's left-to-right order: those entries already differ from the
+// reference by an ulp here and there (it squares with math.pow, the kernels with x * x: tests/helpers.py POW_COLS), they feed
+// no decision, and a strictly sequential sum of K terms was the longest dependent chain of a step.  Both kernel families use
+// the same fixed tree, so their states stay bit-identical to each other:
+//     P_l = x[l] + x[l + 16] + x[l + 32] + ...   (left to right, l = 0..15; entries beyond the length are +0.0)
+//     S   = row_tree_sum_f64(P)
+// The difference to the left-to-right sum is below 1e-14 relative (all terms are >= 0); tests allow 1e-11, the north star 1e-5.
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

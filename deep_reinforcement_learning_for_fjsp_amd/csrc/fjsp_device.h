@@ -133,7 +133,7 @@ struct FixedOffsets {
     static constexpr __host__ __device__ uint32_t e_tend() { return kEnvScalars; }
     static constexpr __host__ __device__ uint32_t e_mjob(uint32_t MP) { return kEnvScalars + 4 * MP; }
     static constexpr __host__ __device__ uint32_t e_jst(uint32_t MP) { return kEnvScalars + 8 * MP; }
-    static constexpr __host__ __device__ uint32_t e_un(uint32_t MP, uint32_t JP) { return kEnvScalars + 8 * MP + 4 * JP; }   // JP is a multiple of 64
+    static constexpr __host__ __device__ uint32_t e_un(uint32_t MP, uint32_t JP) { return (kEnvScalars + 8 * MP + 4 * JP + 7u) & ~7u; }   // JP is a multiple of 16
     static constexpr __host__ __device__ uint32_t e_asg(uint32_t MP, uint32_t JP, uint32_t KP, bool single_job) {
         return e_un(MP, JP) + (single_job ? 8u : 8u * MP * KP);
     }
@@ -141,7 +141,7 @@ struct FixedOffsets {
     // aligned statistics rows behind them
     static constexpr __host__ __device__ uint32_t e_stride_plain(uint32_t MP, uint32_t JP, uint32_t KP, bool single_job) {
         const uint32_t end = single_job ? e_asg(MP, JP, KP, true) + KP : ((e_asg(MP, JP, KP, false) + KP + 63u) & ~63u) + 64u * KP;
-        return (end + 255u) & ~255u;
+        return (end + 127u) & ~127u;       // whole 128-byte lines
     }
 };
 

@@ -352,7 +352,6 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.KC = Kmax <= 64 ? 1 : (Kmax <= 128 ? 2 : 4);
     b.KP = b.KC * kWave;
     b.MP = Mmax;
-    b.JP = ((Jmax + 63) / 64) * 64;
     b.variant = variant;
     b.n_obs = variant == FJSP_VARIANT_SO_FJSSP ? 10 : (dyn ? 15 : 9);
     b.n_static = variant == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 7 : 0;
@@ -360,7 +359,6 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
     b.rng_seed = rng_seed;
     b.mord = (Smax > 1 || dyn) ? 1 : 0; b.SP = Smax; b.RP = Rmax;     // MO_DFJSP always runs on the per-env fluid tables
     b.single_job = (single_job && !b.mord) ? 1 : 0;
-    b.jcap = std::min(b.JP, (Jmax + 15) / 16 * 16);
     b.kmax = Kmax;
     // one 16-lane row per environment (fjsp_group.hip): FJSP_STEP_IMPL=wave keeps such batches on the one-wave-per-environment kernels
     {
@@ -368,6 +366,10 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         b.grp = (b.single_job && Kmax <= 64 && Mmax <= 8 && Jmax <= 15 &&
                  (variant == FJSP_VARIANT_SO_FJSSP || variant == FJSP_VARIANT_MO_FJSSP_DISCRETES) && !(impl && strcmp(impl, "wave") == 0)) ? 1 : 0;
     }
+    // job words per record: a multiple of 64, or 16 in row-kernel batches (at most 15 jobs) -- the dynamic record of such an
+    // environment then spans three 128-byte lines instead of five
+    b.JP = b.grp ? 16 : ((Jmax + 63) / 64) * 64;
+    b.jcap = std::min(b.JP, (Jmax + 15) / 16 * 16);
     if (step_lds_bytes(b) > 160 * 1024) {
         // four environments per workgroup keep their job tables (8 bytes per job) in the CU's 160 KB of LDS
         char msg[200];
@@ -404,7 +406,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         }
         if (dyn) L.e_dyn = take(sizeof(DynScalars) + MP * 4, 8);
         L.e_stats = b.single_job ? 0u : take(KP * 64, 64);
-        L.e_stride = (uint32_t)((o + 255) / 256 * 256);
+        L.e_stride = (uint32_t)((o + 127) / 128 * 128);
     }
     {   // the kernels compute these offsets themselves (FixedOffsets, fjsp_device.h): the two must agree
         using F = FixedOffsets;

@@ -140,8 +140,12 @@ GDEV int first_max(bool mem, uint64_t key, int gb) {
     return hits ? (int)__builtin_ctz(hits) : 255;
 }
 
-template <int MPC>
-__host__ __device__ constexpr size_t group_lds_bytes() { return (size_t)4 * MPC * KS * 8 + 256; }   // + the ring's read-ahead
+// LDS rows per environment: one per machine when Machine.gap_ave's operands are laid out for all of them at once (EARLY), three in
+// the large-batch form (g_gap_ave_lean); the observation needs one
+template <int MPC, bool EARLY>
+__host__ __device__ constexpr int group_rows() { return EARLY ? MPC : 3; }
+template <int MPC, bool EARLY>
+__host__ __device__ constexpr size_t group_lds_bytes() { return (size_t)4 * group_rows<MPC, EARLY>() * KS * 8 + 256; }   // + the ring's read-ahead
 
 // ------------------------------------------------------------------ row state
 struct MoW { double w0, w1, cn, tn; };      // MO_FJSSP_discretes.py:88 weight vector + normalisers (defaults: d_mo == NULL)
@@ -342,35 +346,51 @@ GDEV void g_gap_rows(const GE<V> &e, bool need, const GCols<MPC> &cr) {
     }
 }
 
-// The same with the rows fetched here, slot by slot (large batches: the registers of GCols would cost resident waves, and it is
-// the resident waves that hide the memory there)
-template <int V, int MPC>
-GDEV void g_gap_rows_late(const GE<V> &e, const DevBatch &b, bool need) {
+// Machine.gap_ave (class_FJSSP.py:144-146) of the machines in C for the rows with `need`, large-batch form: the registers
+// of GCols and five LDS rows per environment would cost resident waves, and it is the resident waves that hide the memory
+// there.  So the {arrival, rate} entries are fetched here, for the CANDIDATE machines only, three machines (= three LDS
+// rows per environment) per pass; lanes 0..2 of the row walk them and hand the sums to the machines' lanes.  Returns the
+// machine lanes' gap_ave (lanes of machines in C).
+template <int V>
+GDEV double g_gap_ave_lean(const GE<V> &e, const DevBatch &b, bool need, uint32_t C) {
     const double dt = (double)e.t;
     const double2 *col = reinterpret_cast<const double2 *>(e.ir + b.L.i_col);
+    uint32_t rest = need ? C : 0u;
+    double sum_m = 0.0;
+    while (wave_any(rest != 0)) {
+        // this pass's machines (row-uniform; 8 = none)
+        uint32_t r1 = rest & (rest - 1), r2 = r1 & (r1 - 1);
+        const int m0 = rest ? (int)__builtin_ctz(rest) : 8, m1 = r1 ? (int)__builtin_ctz(r1) : 8, m2 = r2 ? (int)__builtin_ctz(r2) : 8;
 #pragma unroll
-    for (int s = 0; s < GS; ++s) {
-        if (SLOT_ON(e, s) && need) {
-            const uint32_t asg = (e.asgw >> (8 * s)) & 0xFFu;
-            const double2 *rowk = col + (16 * s + e.l) * e.MP;
-            double *dst = e.rows + 16 * s + e.l;
-            double2 ar[MPC];
-#pragma unroll
-            for (int m = 0; m < MPC; ++m) ar[m] = m < e.MP ? rowk[m] : make_double2(0.0, 0.0);
-#pragma unroll
-            for (int m = 0; m < MPC; ++m) {
-                const double un = asg == (uint32_t)m ? ar[m].x - 1.0 : ar[m].x;
-                dst[m * KS] = un - (ar[m].x - dt * ar[m].y);
+        for (int s = 0; s < GS; ++s) {
+            if (SLOT_ON(e, s) && rest != 0) {
+                const int asg = (int)((e.asgw >> (8 * s)) & 0xFFu);
+                const double2 *rowk = col + (16 * s + e.l) * e.MP;
+                double *dst = e.rows + 16 * s + e.l;
+                // (entries of types that cannot run on the machine hold arrival = rate = 0: their gap is +0.0, see g_gap_rows)
+                const double2 a0 = rowk[m0 & 7];
+                const double2 a1 = m1 < 8 ? rowk[m1] : make_double2(0.0, 0.0), a2 = m2 < 8 ? rowk[m2] : make_double2(0.0, 0.0);
+                dst[0] = (asg == m0 ? a0.x - 1.0 : a0.x) - (a0.x - dt * a0.y);          // class_FJSSP.py:198, :304, :137-142
+                dst[KS] = (asg == m1 ? a1.x - 1.0 : a1.x) - (a1.x - dt * a1.y);
+                dst[2 * KS] = (asg == m2 ? a2.x - 1.0 : a2.x) - (a2.x - dt * a2.y);
             }
         }
+        lds_sync();
+        const int mine = e.l == 0 ? m0 : (e.l == 1 ? m1 : (e.l == 2 ? m2 : 8));
+        const double sm = g_walk<V>(e, rest != 0 && mine < 8, e.l);
+        const double s0 = bcd<0>(sm), s1 = bcd<1>(sm), s2 = bcd<2>(sm);
+        sum_m = e.l == m0 ? s0 : (e.l == m1 ? s1 : (e.l == m2 ? s2 : sum_m));
+        lds_sync();
+        rest = r2 & (r2 - 1);
     }
+    return sum_m / ((double)e.mcnt + 1e-18);
 }
 
 // SO_FJSSP.py:300-322 / MO_FJSSP_discretes.py:209-230 machine_select for the rows with `go`.  Machine ids < 8: every
 // CPython set involved iterates in ascending order (fjsp_pyset.h), the candidate lists are bit masks and "first
 // extremum wins" is the lowest machine lane that attains it.  gap_rows: the rows whose LDS rows hold Machine.gap_ave's
 // operands.  Returns m or -1 (status set); *pm_out its processing time.
-template <int V>
+template <int V, bool EARLY>
 GDEV int g_machine_select(GE<V> &e, const DevBatch &b, bool go, int a1, int k_sel, uint32_t em_sel, uint32_t idle, bool gap_rows,
                           int *pm_out) {
     constexpr bool is_mo = V == FJSP_VARIANT_MO_FJSSP_DISCRETES;
@@ -406,8 +426,10 @@ GDEV int g_machine_select(GE<V> &e, const DevBatch &b, bool go, int a1, int k_se
     const bool need3 = m_gave && gap_rows && (C & (C - 1)) != 0;     // (a list of one is returned without ranking it)
     if (wave_any(need3)) {
         // Machine.gap_ave (class_FJSSP.py:144-146): the strictly sequential sum of the machine's row / (n + 1e-18)
-        const double sm = g_walk<V>(e, need3 && e.l < e.M, e.l);
-        g = need3 ? sm / ((double)e.mcnt + 1e-18) : g;
+        double gave;
+        if (EARLY) gave = g_walk<V>(e, need3 && e.l < e.M, e.l) / ((double)e.mcnt + 1e-18);       // (rows: g_gap_rows)
+        else gave = g_gap_ave_lean<V>(e, b, need3, C);
+        g = need3 ? gave : g;
     }
     uint64_t key = sortable(g);
     key = m_pt ? sortable_min_i32(pm) : key;
@@ -552,26 +574,23 @@ GDEV double g_observe(const GE<V> &e, bool on, bool stats_only, long long *tard_
     num = e.l == L_ave2 ? tsum_td : num;
     const double q1 = num / (double)iden;
     const double ave_fr = bcd<L_ave0>(q1), ave_gr = bcd<L_ave1>(q1), ave_td = bcd<L_ave2>(q1);
-    // ---- second pass: squared deviations (math.pow(d, 2), :86-95), population standard deviations
+    // ---- second pass: squared deviations (math.pow(d, 2), :86-95), population standard deviations; their sums by the fixed tree
+    // of fjsp_common.h (row_tree_sum_f64: the one sum that is not taken in the reference's order)
     const double f0 = (0.0 - ave_fr) * (0.0 - ave_fr), f1 = (1.0 - ave_fr) * (1.0 - ave_fr);
+    double p_fr = 0.0, p_gr = 0.0;
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
         if (SLOT_ON(e, s)) {
             const double q0 = __hiloint2double((int)q0h[s], 0);          // 1.0, or 0.0 for padding (x * 0.0 = 0.0: an exact identity)
             const double d2 = grv[s] - ave_gr;
-            e.rows[16 * s + e.l] = (in[s] ? f0 : f1) * q0;
-            e.rows[KS + 16 * s + e.l] = (d2 * d2) * q0;
+            p_fr = p_fr + (in[s] ? f0 : f1) * q0;
+            p_gr = p_gr + (d2 * d2) * q0;
         }
     }
     double d3 = (double)e.tend - ave_td;
     d3 = e.l < e.M ? d3 * d3 : 0.0;
-    double cs_td = 0.0;      // machines in ascending order (+0.0 beyond M)
-    cs_td = cs_td + bcd<0>(d3); cs_td = cs_td + bcd<1>(d3); cs_td = cs_td + bcd<2>(d3); cs_td = cs_td + bcd<3>(d3);
-    cs_td = cs_td + bcd<4>(d3); cs_td = cs_td + bcd<5>(d3); cs_td = cs_td + bcd<6>(d3); cs_td = cs_td + bcd<7>(d3);
-    lds_sync();
-    const double cs2 = g_walk<V>(e, on && (e.l == L_sd0 || e.l == L_sd1), e.l == L_sd1 ? 1 : 0);
-    lds_sync();
-    const double num2 = e.l == L_sd2 ? cs_td : cs2;
+    const double cs_fr = row_tree_sum_f64(p_fr), cs_gr = row_tree_sum_f64(p_gr), cs_td = row_tree_sum_f64(d3);
+    const double num2 = e.l == L_sd0 ? cs_fr : (e.l == L_sd1 ? cs_gr : cs_td);
     const double q2 = sqrt(num2 / (double)(e.l == L_sd2 ? e.M : e.K));
     double cur = (is_ratio && e.done) ? 0.0 : q1;                                 // the ratios are 0 once the episode is over
     cur = (e.l == L_sd0 || e.l == L_sd1 || e.l == L_sd2) ? q2 : cur;
@@ -788,9 +807,8 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
     const uint32_t idle = ~e.busy & e.mmask;
     const int r_sel = g_task_select<V>(e, go, a0, idle);
     GSTAMP(3);
-    if (wave_any(gap_need)) {         // (after task_select: the rows requested at the start of the step have had time to arrive)
-        if (EARLY) g_gap_rows<V, MPC>(e, gap_need, cr);
-        else g_gap_rows_late<V, MPC>(e, b, gap_need);
+    if (EARLY && wave_any(gap_need)) {         // (after task_select: the rows requested at the start of the step have had time to arrive)
+        g_gap_rows<V, MPC>(e, gap_need, cr);
         lds_sync();
     }
 #if defined(FJSP_GABLATE) && FJSP_GABLATE == 2
@@ -803,7 +821,7 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
     const int k_sel = gread((int)(e.jinfo & 0xFFu) + (int)(e.jwl & 0xFFu), rs, e.gb);
     const uint32_t em_sel = greadu(e.emc, rs, e.gb);
     int pm = 0;
-    const int m_sel = g_machine_select<V>(e, b, go, a1, k_sel, em_sel, idle, gap_need, &pm);
+    const int m_sel = g_machine_select<V, EARLY>(e, b, go, a1, k_sel, em_sel, idle, gap_need, &pm);
     *k_out = go ? k_sel : -1; *m_out = m_sel;
 #if defined(FJSP_GABLATE) && FJSP_GABLATE == 3
     e.rng_calls += (uint32_t)(m_sel + pm); return 0.0;                           // diagnostic: stop after machine_select
@@ -858,7 +876,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, co
     }
     GCols<MPC> cr;
     bool gap_need = false;
-    g_open<V>(e, b, wave_id, g_lds, MPC, [&]() __attribute__((always_inline)) {
+    g_open<V>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), [&]() __attribute__((always_inline)) {
         gap_need = env_raw < b.N && rule_wants_gap_ave<V>(araw);
         if (EARLY) g_cols_issue<V, MPC>(e, b, gap_need, cr);
     });
@@ -895,7 +913,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 2) void grollout_kernel(DevBatch b,
     GSTAMP_DECL;
     GSTAMP_BEGIN();
     const int wave_id = (int)blockIdx.x;
-    g_open<V>(e, b, wave_id, g_lds, MPC, []() {});
+    g_open<V>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), []() {});
     MoW mw = {0.0, 1.0, 0.0, 0.0};
     if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES && mo) {
         mw.w0 = mo[(size_t)e.env * 4]; mw.w1 = mo[(size_t)e.env * 4 + 1]; mw.cn = mo[(size_t)e.env * 4 + 2]; mw.tn = mo[(size_t)e.env * 4 + 3];
@@ -945,12 +963,17 @@ static bool group_early(const DevBatch &b) {
     static const int forced = [] { const char *v = getenv("FJSP_GROUP_EARLY"); return v ? atoi(v) : -1; }();
     return forced >= 0 ? forced != 0 : b.N <= 8192;
 }
+// DIAGNOSTIC knob (A/B runs of the occupancy a batch size needs): FJSP_GROUP_LDS_PAD=<bytes> of extra dynamic LDS per wave
+static size_t group_lds_pad() {
+    static const size_t pad = [] { const char *v = getenv("FJSP_GROUP_LDS_PAD"); return v ? (size_t)atol(v) : (size_t)0; }();
+    return pad;
+}
 template <int V>
 static int launch_step_group_v(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                                uint8_t *done, int16_t *trace_km, hipStream_t st) {
     const dim3 grid((unsigned)((b.N + 3) / 4));
     const bool early = group_early(b);
-#define FJSP_GSTEP(MPC, E) hipLaunchKernelGGL((grp::gstep_kernel<V, MPC, E>), grid, dim3(64), grp::group_lds_bytes<MPC>(), st, b, actions, mo, autoreset, state, reward, done, trace_km)
+#define FJSP_GSTEP(MPC, E) hipLaunchKernelGGL((grp::gstep_kernel<V, MPC, E>), grid, dim3(64), (grp::group_lds_bytes<MPC, E>() + group_lds_pad()), st, b, actions, mo, autoreset, state, reward, done, trace_km)
     if (b.MP <= 5) { if (early) FJSP_GSTEP(5, true); else FJSP_GSTEP(5, false); }
     else { if (early) FJSP_GSTEP(8, true); else FJSP_GSTEP(8, false); }
 #undef FJSP_GSTEP
@@ -970,7 +993,7 @@ static int launch_rollout_group_v(const DevBatch &b, const uint8_t *actions, con
                                   double *state_last, hipStream_t st) {
     const dim3 grid((unsigned)((b.N + 3) / 4));
     const bool early = group_early(b);
-#define FJSP_GROLL(MPC, E) hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64), grp::group_lds_bytes<MPC>(), st, b, actions, mo, T, trace_km, reward, state_last)
+#define FJSP_GROLL(MPC, E) hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64), (grp::group_lds_bytes<MPC, E>()), st, b, actions, mo, T, trace_km, reward, state_last)
     if (b.MP <= 5) { if (early) FJSP_GROLL(5, true); else FJSP_GROLL(5, false); }
     else { if (early) FJSP_GROLL(8, true); else FJSP_GROLL(8, false); }
 #undef FJSP_GROLL

@@ -375,12 +375,12 @@ __device__ __forceinline__ void open_env(W<KC, V> &w, const DevBatch *b, int env
             w.jsk[c] = (uint32_t)__shfl((int)jst0, r, 64);
         }
     } else {
-        w.dueL[w.lane] = due0;
+        if (w.lane < JP) w.dueL[w.lane] = due0;       // (row-kernel batches keep 16 job words: JP = 16)
         for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.dueL[n] = reinterpret_cast<const int32_t *>(ir + FO::i_due(KPc))[n];
     }
     if (!load_state) return;
     if (!w.jreg) {
-        w.jstL[w.lane] = jst0;
+        if (w.lane < JP) w.jstL[w.lane] = jst0;
         for (int n = kWave + w.lane; n < w.njobs; n += kWave) w.jstL[n] = reinterpret_cast<const uint32_t *>(er + w.e_jst)[n];
     }
     w.t = uni(sc.t); w.step_count = uni(sc.step_count); w.done = uni(sc.done); w.n_unassigned = uni(sc.n_unassigned);
@@ -1202,10 +1202,10 @@ __device__ __forceinline__ long long observe_prepare(W<KC, V> &w, bool stats_onl
 // One pass of the tail for up to four environments whose LDS slices start at slot0 + e * stride (e < nslots;
 // nslots == 1: the wave's own slice).  Lane L serves slot (L >> 3) & 3 in role L & 7: roles 0..2 walk the
 // finish_rate / gap_rate / time_end rows, roles 4..7 form the delay ratios of :156-165.  First pass: the row
-// sums become the three means (and the ratios are formed -- one division instruction for all of them); second
-// pass (rows now hold the squared deviations): population standard deviations.
+// sums become the three means (and the ratios are formed -- one division instruction for all of them).  (The second
+// pass of the observation -- the standard deviations -- no longer walks: observe_deviations.)
 template <int V, int RING>
-__device__ __forceinline__ void tail_pass(unsigned char *slot0, uint32_t stride, int nslots, int KP, bool second) {
+__device__ __forceinline__ void tail_pass(unsigned char *slot0, uint32_t stride, int nslots, int KP) {
     const int lane = (int)__lane_id();
     const int e = (lane >> 3) & 3, r = lane & 7;
     const bool live = e < nslots;
@@ -1224,32 +1224,47 @@ __device__ __forceinline__ void tail_pass(unsigned char *slot0, uint32_t stride,
     n8 = max(n8, 8);
     const double csum = lds_chain_sum<RING>(row, n8);
     using P = ObsPos<V>;
-    if (!second) {
-        const double ave = (r < 4 ? csum : (double)rnum) / (r < 4 ? (double)len_i : (double)rden);
-        const double out = (r >= 4 && done) ? 0.0 : ave;                   // the ratios are 0 once the episode is over (:156-165)
-        const int pos = r == 0 ? P::ave0 : (r == 1 ? P::ave1 : (r == 2 ? P::ave2 : P::ratio0 + r - 4));
-        if (live && r != 3) scr[pos] = out;
-    } else {
-        const double sd = sqrt(csum / (double)len_i);
-        const int pos = r == 0 ? P::sd0 : (r == 1 ? P::sd1 : P::sd2);
-        if (live && r < 3) scr[pos] = sd;
-    }
+    const double ave = (r < 4 ? csum : (double)rnum) / (r < 4 ? (double)len_i : (double)rden);
+    const double out = (r >= 4 && done) ? 0.0 : ave;                   // the ratios are 0 once the episode is over (:156-165)
+    const int pos = r == 0 ? P::ave0 : (r == 1 ? P::ave1 : (r == 2 ? P::ave2 : P::ratio0 + r - 4));
+    if (live && r != 3) scr[pos] = out;
 }
 
-// Second-pass operands: the squared deviations from the means the first pass left in the scratch row
-// (math.pow(d, 2), :86-95), formed lane-parallel by the environment's own wave.
+// Second pass of the observation by the environment's own wave: the squared deviations from the means the first pass left
+// in the scratch row (math.pow(d, 2), :86-95), their sums by the fixed tree of fjsp_common.h (row_tree_sum_f64: P_l over
+// k = l, l + 16, l + 32, ... left to right, then the 16-lane butterfly -- the same tree the row kernels of fjsp_group.hip
+// use), and the three population standard deviations, written to their places in the scratch row.  Lane (rho, l) of chunk c
+// holds k = 64 c + 16 rho + l: every lane fetches the four rows' values of its column with ds_bpermute and adds them in row
+// order, chunk after chunk, so all four rows hold the same P_l.
 template <int KC, int V>
 __device__ __forceinline__ void observe_deviations(W<KC, V> &w, const double (&frv)[KC], const double (&grv)[KC]) {
     using P = ObsPos<V>;
     const double ave_fr = w.scrL[P::ave0], ave_gr = w.scrL[P::ave1], ave_td = w.scrL[P::ave2];
+    const int l = w.lane & 15;
+    double p_fr = 0.0, p_gr = 0.0;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
         const int k = c * kWave + w.lane;
         const bool valid = k < w.K;
         const double d1 = frv[c] - ave_fr, d2 = grv[c] - ave_gr;
-        w.frL[k] = valid ? d1 * d1 : 0.0; w.grL[k] = valid ? d2 * d2 : 0.0;
-        if (c == 0) { const double d3 = (double)w.tend_m - ave_td; w.tdL[k] = w.lane < w.M ? d3 * d3 : 0.0; }
+        const double v1 = valid ? d1 * d1 : 0.0, v2 = valid ? d2 * d2 : 0.0;
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+            p_fr = p_fr + __shfl(v1, 16 * rho + l, 64);
+            p_gr = p_gr + __shfl(v2, 16 * rho + l, 64);
+        }
     }
+    const double d3 = (double)w.tend_m - ave_td;
+    const double v3 = w.lane < w.M ? d3 * d3 : 0.0;                   // (at most 32 machines: rows 0 and 1)
+    double p_td = 0.0;
+    p_td = p_td + __shfl(v3, l, 64);
+    p_td = p_td + __shfl(v3, 16 + l, 64);
+    const double s_fr = row_tree_sum_f64(p_fr), s_gr = row_tree_sum_f64(p_gr), s_td = row_tree_sum_f64(p_td);
+    // lanes 0..2: one division + square root instruction stream for the three
+    const double num = w.lane == 0 ? s_fr : (w.lane == 1 ? s_gr : s_td);
+    const double sd = sqrt(num / (double)(w.lane == 2 ? w.M : w.K));
+    const int pos = w.lane == 0 ? P::sd0 : (w.lane == 1 ? P::sd1 : P::sd2);
+    if (w.lane < 3) w.scrL[pos] = sd;
 }
 
 // The rest of the observation once the tail has run: static entries, and for SO_SFJSP / MO_DFJSP the
@@ -1314,11 +1329,9 @@ __device__ __forceinline__ long long observe(W<KC, V> &w, bool stats_only = fals
     if (stats_only) return tard_unproc;
     const uint32_t stride = 0;
     wave_sync();
-    tail_pass<V, RING>(reinterpret_cast<unsigned char *>(w.scrL), stride, 1, w.KP, false);
+    tail_pass<V, RING>(reinterpret_cast<unsigned char *>(w.scrL), stride, 1, w.KP);
     wave_sync();
     observe_deviations<KC, V>(w, frv, grv);
-    wave_sync();
-    tail_pass<V, RING>(reinterpret_cast<unsigned char *>(w.scrL), stride, 1, w.KP, true);
     wave_sync();
     observe_finish<KC, V, RING>(w);
     return V == FJSP_VARIANT_SO_SFJSP ? 0 : tard_unproc;      // SO_SFJSP never calls update_parameter: delay_time_sum_unprocessed stays 0
@@ -1696,14 +1709,11 @@ __global__ __launch_bounds__(256, KC >= 4 ? 2 : (KC == 2 ? 3 : 4)) void step_ker
             if (!go && w.lane == 0) w.hdrL[H_N8] = 0;
             tail_sync<true>();
             STAMP(w, 7);
-            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, kWave * KC, false);
+            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, kWave * KC);
             tail_sync<true>();
             STAMP(w, 8);
-            if (go) observe_deviations<KC, V>(w, frv, grv);
-            tail_sync<true>();
+            if (go) { observe_deviations<KC, V>(w, frv, grv); wave_sync(); }     // (the standard deviations: no walk, no barrier)
             STAMP(w, 9);
-            if (wave == walker) tail_pass<V, 8>(fjsp_lds, lds_stride, nslots, kWave * KC, true);
-            tail_sync<true>();
             STAMP(w, 10);
             if (go) {
                 observe_finish<KC, V, 8>(w);

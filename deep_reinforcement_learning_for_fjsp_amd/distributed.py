@@ -63,6 +63,15 @@ def all_reduce_scalar_sum(x):
     return y[0]
 
 
+def all_reduce_scalar_min(x):
+    """Minimum of a 0-dim tensor over ranks (every rank must take the same trainer path: PPOLearner.learn)."""
+    if not is_distributed():
+        return x
+    y = x.detach().clone().reshape(1)
+    dist.all_reduce(y, op=dist.ReduceOp.MIN)
+    return y[0]
+
+
 class FlatGradBucket(object):
     """One contiguous f32 buffer that IS the gradient storage of a network: `zero_()` (in place of
     optimizer.zero_grad()) clears it and makes every parameter's `.grad` a view of its slice, so backward accumulates

@@ -28,7 +28,10 @@ SF_EXACT_COLS = tuple(i for i in range(18) if i not in SF_POW_COLS)
 # MO_DFJSP_breakdown state = [15 obs | 15 deltas]; pow()-derived: ct_std, cro_std, gap_std, gap_m_std (:103-116)
 DYN_POW_COLS = (3, 6, 8, 10, 18, 21, 23, 25)
 DYN_EXACT_COLS = tuple(i for i in range(30) if i not in DYN_POW_COLS)
-POW_RTOL = 1e-12   # north_star allows 1e-5; observed differences are <= a few ulp
+# The standard-deviation entries: the reference squares with math.pow (glibc's pow differs from x * x by 1 ulp in ~0.08 % of
+# arguments) and adds the squares left to right; the kernels square with x * x and add them by a fixed tree (csrc/fjsp_common.h
+# row_tree_sum_f64: no sequential walk for entries that feed no decision).  Both effects are below 1e-14 relative.
+POW_RTOL = 1e-11   # north_star allows 1e-5
 POW_ATOL = 1e-12   # the v(t) - v(t-1) half cancels, so an absolute floor is needed
 
 
@@ -138,5 +141,5 @@ def assert_state_close(got, want, what="", mo=False, sf=False, dyn=False):
     for c in pw:
         atol = POW_ATOL
         if c >= first_delta and (c - shift) in pw:
-            atol = max(atol, 2e-15 * float(np.max(np.abs(want[..., c - shift]))) if want.size else atol)
+            atol = max(atol, 2e-14 * float(np.max(np.abs(want[..., c - shift]))) if want.size else atol)
         np.testing.assert_allclose(got[..., c], want[..., c], rtol=POW_RTOL, atol=atol, err_msg="%s (state entry %d)" % (what, c))

@@ -486,6 +486,13 @@ def test_fused_ppo_learning_matches_autograd(torch_gpu):
             for pr, pf in zip(nr.parameters(), nf.parameters()):
                 np.testing.assert_allclose(pf.detach().cpu().numpy(), pr.detach().cpu().numpy(), rtol=rtol, atol=atol,
                                            err_msg="%s after %d iteration(s)" % (name, iters))
+    # the trainer path is fixed at the first learn(): a later, smaller batch stays on the fused trainer (one set of Adam
+    # moments), it does not wake the torch optimisers up
+    small = slice(0, 2000)
+    fus.learn(states[small], actions[small], old_lp[small], returns[small], valid[small])
+    assert fus._path == "fused" and fus._use_fused and len(fus.actor_optimizer.state) == 0 and len(fus.critic_optimizer.state) == 0
+    ref.learn(states, actions, old_lp, returns, valid)
+    assert ref._path == "eager" and not ref._use_fused
     # the parameters live in ONE flat buffer (the all-reduce bucket), the module still owns them
     actor_tr, _ = fus._fused_nets()
     assert actor_tr.flat.numel() == sum(p.numel() for p in fus.actor_new.parameters())

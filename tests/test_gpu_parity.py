@@ -834,8 +834,8 @@ def test_async_arrival_service_keeps_every_env_on_its_own_trajectory(torch_gpu):
         cursor += took.long()
         done_prev = done_prev | ((ready != 0) & (d != 0))
         calls += 1
+        parked_seen = max(parked_seen, b.parked)          # (a host-side counter: no device round trip)
         if calls % 25 == 0:
-            parked_seen = max(parked_seen, b.parked)
             if bool(done_prev.all()):
                 break
         assert calls < 6000

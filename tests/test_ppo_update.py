@@ -114,6 +114,11 @@ def _worker(rank, world, port, tmp):
     L = PPOLearner(20, 30, device="cpu", seed=11)
     L.learn(data["states"][:, lo:hi], data["actions"][:, lo:hi], data["logp"][:, lo:hi], data["returns"][:, lo:hi],
             data["valid"][:, lo:hi])
+    # the trainer path (one optimiser state per learner) was agreed between the ranks at this first round: the minimum
+    # sample count over the ranks decides, not the rank's own shard
+    from deep_reinforcement_learning_for_fjsp_amd import distributed as fdist
+    assert L._path == "eager"
+    assert float(fdist.all_reduce_scalar_min(torch.tensor(float(100 + rank)))) == 100.0
     torch.save([p.detach() for p in list(L.actor_new.parameters()) + list(L.critic.parameters())],
                os.path.join(tmp, "params_rank%d.pt" % rank))
     dist.barrier()
@@ -143,6 +148,20 @@ def test_data_parallel_round_equals_single_process(tmp_path):
     for a, b, w in zip(r0, r1, want):
         assert torch.equal(a, b)                                   # ranks stay in lock-step
         torch.testing.assert_close(a, w, rtol=2e-4, atol=2e-5)      # == single process up to f32 summation order
+
+
+def test_trainer_path_is_fixed_at_the_first_round():
+    """A learner keeps ONE optimiser state: the path chosen at the first learn() stands for every later batch size."""
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import PPOLearner
+    torch.manual_seed(3)
+    L = PPOLearner(20, 30, device="cpu", seed=4)
+    assert L._path is None
+    for n in (64, 7, 300):
+        st = torch.randn(n, 20)
+        a, lp = L.act(st)
+        L.learn(st, a, lp, torch.randn(n), torch.ones(n))
+        assert L._path == "eager" and not L._use_fused
+    assert len(L.actor_optimizer.state) > 0
 
 
 def test_tall_linear_split_k_weight_gradient():

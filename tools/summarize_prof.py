@@ -32,5 +32,6 @@ for tag in ("pmc_sq", "pmc_fetch", "pmc_write"):
 json.dump(pm, open(os.path.join(out, "pmc_means.json"), "w"), indent=1)
 for r in rows:
     print(r["Name"].split("(")[0][-30:], r["Calls"], r["AverageNs"])
-sk = pm.get("fjsp::step_kernel<1, 0, true>", {})
-print("step_kernel<1, 0, true> FETCH_SIZE KiB", sk.get("FETCH_SIZE"), "WRITE_SIZE KiB", sk.get("WRITE_SIZE"))
+for k, sk in pm.items():
+    if "step_kernel" in k:
+        print(k, "FETCH_SIZE KiB", sk.get("FETCH_SIZE"), "WRITE_SIZE KiB", sk.get("WRITE_SIZE"))

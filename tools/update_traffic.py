@@ -19,12 +19,13 @@ from bench import csrc_hash  # noqa: E402
 src = sys.argv[1]
 tag = os.path.basename(src.rstrip("/")).replace("prof_", "")
 pm = json.load(open(os.path.join(src, "pmc_means.json")))
-sk = pm["fjsp::step_kernel<1, 0, true>"]
+skey = [k for k in pm if "gstep_kernel" in k or "step_kernel<1, 0, true>" in k][0]
+sk = pm[skey]
 fetch = sk["FETCH_SIZE"] * 1024 * 2.0
 write = sk["WRITE_SIZE"] * 1024
 bench = json.load(open(os.path.join(src, "bench.json")))
 out = {
-    "kernel": "fjsp::step_kernel<1, 0, true>",
+    "kernel": skey,
     "envs": 4096,
     "fetch_size_kib_per_launch_reported": sk["FETCH_SIZE"],
     "write_size_kib_per_launch_reported": sk["WRITE_SIZE"],
@@ -40,7 +41,7 @@ out = {
     "insts_per_wave_step": {k: sk[k] / sk["SQ_WAVES"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
                                                                 "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if k in sk},
 }
-rk = pm.get("fjsp::rollout_kernel<1, 0>")
+rk = pm.get([k for k in pm if "rollout_kernel" in k][0]) if [k for k in pm if "rollout_kernel" in k] else None
 if rk and bench.get("fused"):
     steps_per_wave = bench["fused"]["env_steps_per_launch"] / rk["SQ_WAVES"]
     insts = sum(rk.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
