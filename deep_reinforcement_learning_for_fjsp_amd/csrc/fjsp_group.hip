@@ -189,10 +189,22 @@ template <int MPC>
 struct GCols { double2 c[GS][MPC]; };
 
 // the current operation type of every job lane: k = first + next stage, and its static data out of the operation slots
-template <int V>
-GDEV void g_gather_current(GE<V> &e, bool want_rsum) {
+template <int V, bool EARLY>
+GDEV void g_gather_current(GE<V> &e, const DevBatch &b, bool want_rsum) {
     const int kc = (int)(e.jinfo & 0xFFu) + (int)(e.jwl & 0xFFu);
     const int src = kc & 15, sl = (kc >> 4) & 3;
+    if (!EARLY) {
+        // large batches: the fluid numbers of the operation slots are not kept in registers between the start of a step and its
+        // observation (resident waves hide the second fetch; the registers would cost a wave per SIMD): every job lane fetches
+        // {fluid_rate_sum, fluid_time_sum} of its current operation type, the elig | fmask word comes out of the slots
+        const double2 rt = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + sl * 512 + 256)[src];
+        uint32_t a[GS];
+#pragma unroll
+        for (int s = 0; s < GS; ++s) { a[s] = 0; if (SLOT_ON(e, s)) a[s] = greadu(e.em[s], src, e.gb); }
+        e.emc = pick_slot(a, sl);
+        e.rsumc = rt.x; e.tsumc = rt.y;
+        return;
+    }
     uint32_t a[GS], tl[GS], th[GS];
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
@@ -510,8 +522,8 @@ GDEV void g_dispatch_advance(GE<V> &e, bool go, int r_sel, int k_sel, int m_sel,
 // observation in the observation lanes (lane (8 + i) & 15 holds entry i) and delay_time_sum_unprocessed (:110-122)
 // through *tard_unproc; only the rows with `on` walk their sums (the others' results are garbage nobody reads).
 // stats_only: a step that hands no state back needs the tardiness for its reward and nothing else.
-template <int V>
-GDEV double g_observe(const GE<V> &e, bool on, bool stats_only, long long *tard_unproc) {
+template <int V, bool EARLY>
+GDEV double g_observe(const GE<V> &e, const DevBatch &b, bool on, bool stats_only, long long *tard_unproc) {
     using P = ObsPos<V>;
     constexpr int L_ave0 = (P::ave0 + 8) & 15, L_ave1 = (P::ave1 + 8) & 15, L_ave2 = (P::ave2 + 8) & 15;
     constexpr int L_sd0 = (P::sd0 + 8) & 15, L_sd1 = (P::sd1 + 8) & 15, L_sd2 = (P::sd2 + 8) & 15;
@@ -536,20 +548,31 @@ GDEV double g_observe(const GE<V> &e, bool on, bool stats_only, long long *tard_
     bool in[GS];
     double grv[GS];
     uint32_t q0h[GS];
+    double2 rt[GS];
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+        rt[s] = make_double2(e.rsum[s], e.tsum[s]);
+        if (!EARLY) {       // (large batches: the fluid numbers are fetched again, see g_gather_current)
+            rt[s] = make_double2(0.0, 0.0);
+            if (SLOT_ON(e, s) && 16 * s + e.l < b.kmax) rt[s] = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + s * 512 + 256)[e.l];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
         in[s] = false; grv[s] = 0.0; q0h[s] = 0;
         if (SLOT_ON(e, s)) {
             const uint32_t kb = e.kB[s];
-            const uint32_t njk = greadu(e.jwl, (int)((kb >> 16) & 0xFu), e.gb) & 0xFFu;
+            const int kind = (int)((kb >> 16) & 0xFu);
+            const uint32_t njk = greadu(e.jwl, kind, e.gb) & 0xFFu;
+            const int due_s = EARLY ? e.due[s] : gread(e.duej, kind, e.gb);       // (one job per kind: the type's due date is its job's)
             in[s] = njk <= (kb & 0xFFu);
-            const double de = (td + e.tsum[s]) - (double)e.due[s];
+            const double de = (td + rt[s].y) - (double)due_s;
             const bool cnte = in[s] && de > 0.0;
             c1 += cnte ? 1u << 24 : 0u;
             c3 += (cnte && ((kb >> 24) & 1u)) ? 1u << 24 : 0u;
             q0h[s] = (kb >> 24) & 2u ? 0x3FF00000u : 0u;                                // Q0 = jobs of the kind: 1.0, or 0.0 for padding
             const double q0 = __hiloint2double((int)q0h[s], 0);
-            const double fq = q0 - e.rsum[s] * td;                                      // fluid_unprocessed_number (:239-240)
+            const double fq = q0 - rt[s].x * td;                                        // fluid_unprocessed_number (:239-240)
             grv[s] = (in[s] ? 1.0 : 0.0) - fq;                                          // gap_rate class_FJSSP.py:66-68 (x / 1.0 == x)
             e.rows[16 * s + e.l] = grv[s];
         }
@@ -600,10 +623,10 @@ GDEV double g_observe(const GE<V> &e, bool on, bool stats_only, long long *tard_
 
 // v(t-1) of the state vector is the observation of the environment as a step finds it; steps that handed no state back did
 // not keep it current (fjsp_kernels.hip obs_refresh).  (Inline like everything else: a call would pin the row state in scratch.)
-template <int V>
-GDEV void g_obs_refresh(GE<V> &e, bool on) {
+template <int V, bool EARLY>
+GDEV void g_obs_refresh(GE<V> &e, const DevBatch &b, bool on) {
     long long tu;
-    const double v = g_observe<V>(e, on, false, &tu);
+    const double v = g_observe<V, EARLY>(e, b, on, false, &tu);
     if (on && ((e.l - 8) & 15) < kNObs<V>) e.obs_prev = v;
     if (on) e.misc &= ~(1u << 24);
 }
@@ -647,7 +670,7 @@ GDEV void g_emit(GE<V> &e, bool on, double cur, const double *sstate, double *st
 // Bind the four rows of a wave to their records and bring the environments in: every load is independent of the
 // others (bounds come from the kernel arguments), one memory round trip.  `between` runs after the loads are out and
 // before they are waited for (the kernels request the gap_ave rows there).
-template <int V, class F>
+template <int V, bool EARLY, class F>
 GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, int rows_per_env, F &&between) {
     using FO = FixedOffsets;
     const int lane = (int)__lane_id();
@@ -674,7 +697,7 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
         if (16 * s + e.l < b.kmax) {
             const unsigned char *slot = op + s * 512;
             A[s] = reinterpret_cast<const uint4 *>(slot)[e.l];
-            B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];
+            if (EARLY) B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];      // (large batches: g_gather_current, g_observe)
         }
     }
     const uint32_t asgw = reinterpret_cast<const uint32_t *>(er + FO::e_asg((uint32_t)MP, (uint32_t)JP, 64u, true))[e.l];
@@ -796,13 +819,13 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
     return 0.0;                                                                   // diagnostic: state in / state out only
 #endif
     const bool stale = (e.misc >> 24) & 1u;
-    if (need_obs && wave_any(go && stale)) g_obs_refresh<V>(e, go && stale);
+    if (need_obs && wave_any(go && stale)) g_obs_refresh<V, EARLY>(e, b, go && stale);
     if (is_mo) {                     // flat action -> self.actions[action] (MO_FJSSP_discretes.py:26,92)
         e.status |= (go && a0 >= 18) ? (uint32_t)FJSP_ST_BAD_TASK_RULE : 0u;     // IndexError
         go = go && a0 < 18;
         a1 = a0 % 3; a0 = a0 / 3;
     }
-    g_gather_current<V>(e, wave_any(go && a0 == 2));
+    g_gather_current<V, EARLY>(e, b, wave_any(go && a0 == 2));
     GSTAMP(2);
     const uint32_t idle = ~e.busy & e.mmask;
     const int r_sel = g_task_select<V>(e, go, a0, idle);
@@ -836,9 +859,9 @@ GDEV double g_step(GE<V> &e, const DevBatch &b, bool go_in, int a0, int a1, cons
     e.step_count += go ? 1 : 0;                                                  // :252
     long long tard_unproc = 0;
 #if defined(FJSP_GABLATE) && FJSP_GABLATE == 5
-    const double cur = g_observe<V>(e, go, true, &tard_unproc);               // diagnostic: statistics only, no observation
+    const double cur = g_observe<V, EARLY>(e, b, go, true, &tard_unproc);     // diagnostic: statistics only, no observation
 #else
-    const double cur = g_observe<V>(e, go, !need_obs, &tard_unproc);          // :256
+    const double cur = g_observe<V, EARLY>(e, b, go, !need_obs, &tard_unproc);   // :256
 #endif
     GSTAMP(7);
     if (need_obs) g_emit<V>(e, go, cur, reinterpret_cast<const double *>(e.ir + b.L.i_ss), state_out);
@@ -859,7 +882,7 @@ GDEV bool rule_wants_gap_ave(uint32_t araw) {
 // EARLY: request the gap_ave rows together with the state (small batches: a wave is alone on its SIMD and nothing else hides
 // the memory round trip); otherwise they are fetched where they are used and the kernel keeps to 128 registers
 template <int V, int MPC, bool EARLY>
-__global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
+__global__ __launch_bounds__(64, EARLY ? 1 : (V == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 3 : 4)) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
                                                    double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     GE<V> e;
     GSTAMP_DECL;
@@ -876,7 +899,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, co
     }
     GCols<MPC> cr;
     bool gap_need = false;
-    g_open<V>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), [&]() __attribute__((always_inline)) {
+    g_open<V, EARLY>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), [&]() __attribute__((always_inline)) {
         gap_need = env_raw < b.N && rule_wants_gap_ave<V>(araw);
         if (EARLY) g_cols_issue<V, MPC>(e, b, gap_need, cr);
     });
@@ -913,7 +936,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 2) void grollout_kernel(DevBatch b,
     GSTAMP_DECL;
     GSTAMP_BEGIN();
     const int wave_id = (int)blockIdx.x;
-    g_open<V>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), []() {});
+    g_open<V, EARLY>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), []() {});
     MoW mw = {0.0, 1.0, 0.0, 0.0};
     if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES && mo) {
         mw.w0 = mo[(size_t)e.env * 4]; mw.w1 = mo[(size_t)e.env * 4 + 1]; mw.cn = mo[(size_t)e.env * 4 + 2]; mw.tn = mo[(size_t)e.env * 4 + 3];
