@@ -98,16 +98,67 @@ def zscore_returns(G, valid):
     return (G - mean) / (std + 1e-5) * m
 
 
-def a2c_losses(task_log_prob, machine_log_prob, values, returns, valid):
-    """:403-418 averaged over the batch: every environment's episode contributes the MEAN over its own
-    steps (one worker's loss), the batch loss is the mean over environments with at least one step."""
+def a2c_losses(task_log_prob, machine_log_prob, values, returns, valid, form="reference"):
+    """:403-418 averaged over the batch: every environment's episode contributes one worker's loss, the batch loss is the
+    mean over environments with at least one step.
+
+    form "reference" (default) is the arithmetic the reference ships: the critic's outputs are [1, 1] tensors, so
+    `torch.cat(self.critic_outputs)` is [T, 1] and `torch.Tensor(returns) - critic_values` (:405) BROADCASTS to [T, T] --
+    entry (a, b) = G_b - V_a.  The critic loss is therefore the mean over all PAIRS of (G_b - V_a)^2, and the actors'
+    `-log_prob * advantages` (:414-416, [T] * [T, T]) is the mean over pairs of -log_prob_b (G_b - V_a): the baseline of
+    every step is the episode's MEAN value, not the value of its own state.  Computed here without the T x T matrix:
+        mean_ab (G_b - V_a)^2 = mean(G^2) - 2 mean(G) mean(V) + mean(V^2),   mean_ab -lp_b (G_b - V_a) = -mean_b lp_b (G_b - mean(V))
+    (fixtures generated by the reference's own methods pin it: tests/golden/make_agent_fixtures_ref.py).
+    form "per_step": the textbook advantage G_t - V(s_t) per step (what round 2 shipped)."""
     m = (valid > 0).to(values.dtype)
     n = m.sum(0)
     live = (n > 0).to(values.dtype)
     n = n.clamp(min=1)
-    adv = (returns - values).detach()
     per_env = lambda x: ((x * m).sum(0) / n * live).sum() / live.sum().clamp(min=1)
-    return per_env((returns - values) ** 2), per_env(-1.0 * task_log_prob * adv), per_env(-1.0 * machine_log_prob * adv)
+    if form == "per_step":
+        adv = (returns - values).detach()
+        return per_env((returns - values) ** 2), per_env(-1.0 * task_log_prob * adv), per_env(-1.0 * machine_log_prob * adv)
+    mean_t = lambda x: (x * m).sum(0) / n                                   # per environment, over its own steps
+    g1, g2, v1, v2 = mean_t(returns), mean_t(returns ** 2), mean_t(values), mean_t(values ** 2)
+    over_envs = lambda x: (x * live).sum() / live.sum().clamp(min=1)
+    critic = over_envs(g2 - 2.0 * g1 * v1 + v2)
+    adv = (returns - v1.detach().unsqueeze(0))                              # G_b - mean_a V_a
+    return critic, per_env(-1.0 * task_log_prob * adv), per_env(-1.0 * machine_log_prob * adv)
+
+
+class SharedAdamRule(torch.optim.Optimizer):
+    """The update rule of the reference's SharedAdam (utilities/Utility_Functions.py:55-112), which is NOT torch.optim.Adam's:
+    eps is added to sqrt(v) BEFORE the bias correction of the second moment,
+        p -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps),
+    so at the reference's eps = 1e-4 the first steps behave like Adam with an eps some 30 times larger.  (What the reference
+    shares between processes -- the moments in shared memory -- is replaced by the gradient all-reduce of the batched trainer.)"""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.steps = 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                self.state[p]["exp_avg"] = torch.zeros_like(p)
+                self.state[p]["exp_avg_sq"] = torch.zeros_like(p)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import math
+        self.steps += 1
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            gs = [p.grad for p in ps]
+            ms = [self.state[p]["exp_avg"] for p in ps]
+            vs = [self.state[p]["exp_avg_sq"] for p in ps]
+            b1, b2 = group["betas"]
+            torch._foreach_mul_(ms, b1); torch._foreach_add_(ms, gs, alpha=1 - b1)
+            torch._foreach_mul_(vs, b2); torch._foreach_addcmul_(vs, gs, gs, value=1 - b2)
+            den = torch._foreach_sqrt(vs)
+            torch._foreach_add_(den, group["eps"])
+            step_size = group["lr"] * math.sqrt(1 - b2 ** self.steps) / (1 - b1 ** self.steps)
+            torch._foreach_addcdiv_(ps, ms, den, value=-step_size)
 
 
 class DA3C(Base_Agent, Config):
@@ -120,7 +171,7 @@ class DA3C(Base_Agent, Config):
     OBJECTIVE_KEY = {0: "completion_time", 1: "delay_time_sum", 2: "energy_consumption"}
 
     def __init__(self, make_train_env, test_env, reward_policy=0, hidden_size=200, hidden_layer=3, hyper=None,
-                 seed=0, max_steps=4096, state_size=30, actions_size=(12, 10)):
+                 seed=0, max_steps=4096, state_size=30, actions_size=(12, 10), loss_form="reference"):
         Base_Agent.__init__(self)
         Config.__init__(self)
         self.hp = dict(self.hyper_parameters["DA3C"])
@@ -139,7 +190,8 @@ class DA3C(Base_Agent, Config):
         torch.random.set_rng_state(rng)
         lr = self.hp["learning_rate"]
         self.nets = (self.actor_task_model, self.actor_machine_model, self.critic_model)
-        self.optimizers = tuple(Adam(n.parameters(), lr=lr, eps=1e-4) for n in self.nets)
+        self.loss_form = loss_form           # a2c_losses: "reference" (the arithmetic the reference ships) or "per_step"
+        self.optimizers = tuple(SharedAdamRule(n.parameters(), lr=lr, eps=1e-4) for n in self.nets)      # :112-114
         self.buckets = tuple(fdist.FlatGradBucket(n.parameters()) for n in self.nets)
         self.max_steps = max_steps
         self.objective_min = float("inf")
@@ -216,7 +268,7 @@ class DA3C(Base_Agent, Config):
         lp_t = Categorical(self.actor_task_model(flat)).log_prob(a_t).reshape(T, N)
         lp_m = Categorical(self.actor_machine_model(torch.cat([flat, a_t.float().unsqueeze(1)], 1))).log_prob(a_m).reshape(T, N)
         values = self.critic_model(flat).reshape(T, N)
-        c_loss, t_loss, m_loss = a2c_losses(lp_t, lp_m, values, G, valid)
+        c_loss, t_loss, m_loss = a2c_losses(lp_t, lp_m, values, G, valid, self.loss_form)
         w = fdist.world_size()
         for net, opt, bucket, loss in zip(self.nets, self.optimizers, self.buckets, (t_loss, m_loss, c_loss)):
             bucket.zero_()                            # (gradients live in the all-reduce bucket)

@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""Fixtures that pin the off-policy / actor-critic counterparts to the reference's update
-arithmetic: tests/golden/agent_updates.npz.
+"""CROSS-CHECK of tests/golden/make_agent_fixtures_ref.py (round 3), which generates tests/golden/agent_updates.npz by
+calling the reference's own agent classes; this file is the round-2 hand transcription of the same updates and is no
+longer what writes the fixtures (`make_agent_fixtures_ref.py --compare` prints the differences between the two: none for
+DDQN and SAC-discrete; for A3C the transcription had (a) squeezed the critic's [1, 1] outputs, which the reference does not
+-- its advantages broadcast to [T, T] -- and (b) taken SharedAdam for torch.optim.Adam, which it is not).
+
+Original header: fixtures that pin the off-policy / actor-critic counterparts to the reference's update
+arithmetic.
 
 The reference's agent modules cannot be imported (visdom / nn_builder at import time, `D:/` paths),
 so what is below is a torch-CPU TRANSCRIPTION of the three update paths, statement by statement, each citing the

@@ -1,7 +1,9 @@
-"""The DDQN / SAC-discrete / A3C counterparts against tests/golden/agent_updates.npz: losses and every parameter
-after ONE update, computed by a torch-CPU transcription of the reference's update code at fixed weights
-(tests/golden/make_agent_fixtures.py, which cites the reference lines).  The same check runs on the CPU (here) and
-on the MI355X (-m gpu): same weights, same batch, f32 tolerance."""
+"""The DDQN / SAC-discrete / A3C / PPO counterparts against tests/golden/agent_updates.npz and ppo_update.npz: losses and
+every parameter after ONE update (PPO: one learning round), computed by THE REFERENCE'S OWN agent classes at fixed weights
+(tests/golden/make_agent_fixtures_ref.py imports agents/DDQN/DDQN.py, agents/HMPSAC/SAC_Discrete.py, A3C_v5.1.py and
+agents/MPPPO/MPPPO.py from /root/reference in the build container and calls their learn / loss / optimisation-step methods;
+make_agent_fixtures.py, the round-2 transcription, stays as its cross-check).  The same check runs on the CPU (here) and on
+the MI355X (-m gpu): same weights, same batch, f32 tolerance."""
 import os
 import re
 
@@ -101,14 +103,42 @@ def _a3c(device):
         _assert_module(net, fx, "a3c/%s1" % name, "A3C %s net after one worker update" % name)
 
 
-@pytest.mark.parametrize("case", [_ddqn, _sac, _a3c], ids=["ddqn", "sac", "a3c"])
-def test_update_matches_the_reference_transcription_on_cpu(case):
+def _ppo(device):
+    """PPO.run_one_policy_network's learning round (MPPPO.py:254-270,301-370) by the reference's methods, as shipped: the
+    critic receives no gradient there (:319), so the recorded critic is unchanged -- PPOLearner(train_critic=False)."""
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import PPOLearner, discounted_returns, normalise_returns
+    fx = np.load(os.path.join(os.path.dirname(FIX), "ppo_update.npz"))
+    lr, gamma, clip_eps, clip_norm, iters = fx["ppo/hyper"]
+    L = PPOLearner(25, 18, 16, 2, 2, device=device, seed=3, train_critic=False,
+                   hyper={"learning_rate": float(lr), "discount_rate": float(gamma), "clip_epsilon": float(clip_eps),
+                          "gradient_clipping_norm": float(clip_norm), "learning_iterations_per_round_critic": int(iters),
+                          "learning_iterations_per_round_actor": int(iters)})
+    _load(L.actor_new, fx, "ppo/actor0", device); _load(L.actor_old, fx, "ppo/actor0", device); _load(L.critic, fx, "ppo/critic0", device)
+    states, rewards, old_lp = _t(fx, "ppo/states", device), _t(fx, "ppo/rewards", device), _t(fx, "ppo/old_log_prob", device)
+    actions = torch.from_numpy(fx["ppo/actions"]).to(device)
+    T = states.shape[0]
+    valid = torch.ones(T, 1, device=device)
+    G = discounted_returns(rewards[:, None], valid, float(gamma))                                   # :301-312
+    np.testing.assert_array_equal(G[:, 0].cpu().numpy(), fx["ppo/returns_raw"])                     # same f32 recurrence: same bits
+    Gn = normalise_returns(G, valid)                                                                # :258-261
+    np.testing.assert_allclose(Gn[:, 0].cpu().numpy(), fx["ppo/returns"], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        adv = Gn[:, 0] - L.critic(states).squeeze(1)                                                # :263
+    np.testing.assert_allclose(adv.cpu().numpy(), fx["ppo/advantages"], rtol=1e-5, atol=2e-6)
+    L.learn(states[:, None, :], actions[:, None], old_lp[:, None], Gn, valid)                       # :314-323
+    _assert_module(L.actor_new, fx, "ppo/actor1", "PPO actor after one learning round")
+    _assert_module(L.critic, fx, "ppo/critic1", "PPO critic (no gradient reaches it in the reference as shipped)")
+    _assert_module(L.actor_old, fx, "ppo/actor1", "PPO old policy after equalise_policies")
+
+
+@pytest.mark.parametrize("case", [_ddqn, _sac, _a3c, _ppo], ids=["ddqn", "sac", "a3c", "ppo"])
+def test_update_matches_the_reference_classes_on_cpu(case):
     torch.set_num_threads(1)
     case("cpu")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [_ddqn, _sac, _a3c], ids=["ddqn", "sac", "a3c"])
-def test_update_matches_the_reference_transcription_on_gpu(case):
+@pytest.mark.parametrize("case", [_ddqn, _sac, _a3c, _ppo], ids=["ddqn", "sac", "a3c", "ppo"])
+def test_update_matches_the_reference_classes_on_gpu(case):
     assert torch.cuda.is_available()
     case("cuda:0")

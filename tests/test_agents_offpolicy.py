@@ -128,8 +128,10 @@ def test_a2c_returns_and_losses_per_episode():
     Z = zscore_returns(G, valid)
     lp_t, lp_m = torch.from_numpy(rs.randn(T, N)), torch.from_numpy(rs.randn(T, N))
     values = torch.from_numpy(rs.randn(T, N))
-    c, lt, lm = a2c_losses(lp_t, lp_m, values, Z, valid)
+    c, lt, lm = a2c_losses(lp_t, lp_m, values, Z, valid, form="per_step")
+    c2, lt2, lm2 = a2c_losses(lp_t, lp_m, values, Z, valid)        # the reference's arithmetic: [T] - [T, 1] broadcasts to [T, T]
     wc, wt, wm, live = 0.0, 0.0, 0.0, 0
+    rc, rt, rm = 0.0, 0.0, 0.0
     for e in range(N):
         L = lens[e]
         if L == 0:
@@ -145,9 +147,14 @@ def test_a2c_returns_and_losses_per_episode():
         np.testing.assert_allclose(Z[:L, e].numpy(), z, rtol=1e-9, atol=1e-12)
         adv = z - values[:L, e].numpy()
         wc += np.mean(adv ** 2); wt += np.mean(-lp_t[:L, e].numpy() * adv); wm += np.mean(-lp_m[:L, e].numpy() * adv)
+        # A3C_v5.1.py:403-417 as shipped: critic_values is [T, 1], so returns - critic_values is the [T, T] matrix G_b - V_a
+        pair = torch.from_numpy(z) - values[:L, e].reshape(L, 1)
+        rc += float((pair ** 2).mean()); rt += float((-1.0 * lp_t[:L, e] * pair).mean()); rm += float((-1.0 * lp_m[:L, e] * pair).mean())
         live += 1
     assert math.isclose(float(c), wc / live, rel_tol=1e-9)
     assert math.isclose(float(lt), wt / live, rel_tol=1e-9) and math.isclose(float(lm), wm / live, rel_tol=1e-9)
+    assert math.isclose(float(c2), rc / live, rel_tol=1e-9)
+    assert math.isclose(float(lt2), rt / live, rel_tol=1e-9) and math.isclose(float(lm2), rm / live, rel_tol=1e-9)
 
 
 # ---------------------------------------------------------------------------------------------
