@@ -705,6 +705,59 @@ def test_shards_concatenate_to_the_unsharded_batch(torch_gpu):
         assert np.array_equal(got[3], ref[3][lo:hi]) and np.array_equal(got[4], ref[4][lo:hi])
 
 
+def test_config3_per_gpu_workload_in_eight_shards(torch_gpu):
+    """BASELINE configs[3]: 32 768 envs sharded 8-way.  The per-GPU workload of that configuration on ONE GPU: eight
+    shards of 4 096 envs built the way eight ranks build them (generator seeds, action tensor and random.choice streams from
+    the GLOBAL env id), 24 autoreset steps each.  Checked: (a) one shard against the unsharded 32 768-env batch, bit for bit
+    (states, rewards, chosen pairs) -- the unsharded batch runs the large-batch variant of the row kernels, the shard the
+    small-batch one, so this is also their equality at full size; (b) an oracle replay of a sample of envs across all
+    shards; (c) size-independent properties on all 32 768 envs: no error status, one dispatch per step, rewards telescope
+    to minus the tardiness of the finished episodes."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, global_actions
+    N, W, T = 32768, 8, 24
+    per = N // W
+    prm = fi.bench_10x5_params()
+
+    def play(n, first_env, keep_states):
+        insts = fi.InstanceSet(n).generate_range(1000 + first_env, prm).solve_fluid()
+        b = EnvBatch(insts, n, rng_seed=20260, first_env=first_env)
+        a = torch.from_numpy(global_actions(4242, first_env, n, T, 6, 5)).to(b.device)
+        st0 = b.reset().clone()
+        tr = torch.zeros(n, 2, dtype=torch.int16, device=b.device)
+        rws, kms, sts = [], [], []
+        for t in range(T):
+            s, r, _ = b.step(a[t], autoreset=True, trace_out=tr)
+            rws.append(r.clone()); kms.append(tr.clone())
+            if keep_states:
+                sts.append(s.clone())
+        fin = b.read()
+        assert int((fin["status"] != 0).sum()) == 0
+        return insts, b, st0, torch.stack(rws), torch.stack(kms), (torch.stack(sts) if keep_states else None), fin
+
+    _, whole_b, st0_w, rw_w, km_w, _, fin_w = play(N, 0, False)
+    assert whole_b.kernel_family == 1
+    assert bool((km_w >= 0).all())                                     # every env dispatched one operation per step
+    rs = np.random.RandomState(5)
+    for g in range(W):
+        lo = g * per
+        insts, b, st0, rw, km, _, fin = play(per, lo, False)
+        assert torch.equal(st0, st0_w[lo:lo + per]) and torch.equal(rw, rw_w[:, lo:lo + per]) and torch.equal(km, km_w[:, lo:lo + per]), g
+        for key in ("delay_time_sum", "makespan", "step_time", "step_count"):
+            assert torch.equal(fin[key], fin_w[key][lo:lo + per]), (g, key)
+        # oracle replay of two envs of this shard: its first T steps (no episode of the 10x5 workload is shorter than 30)
+        acts_h = global_actions(4242, lo, per, T, 6, 5)
+        for e in rs.randint(0, per, 2):
+            a = insts.arrays(int(e))
+            want = H.play_oracle(a, a.x, np.concatenate([acts_h[:, e], np.zeros((64, 2), np.uint8)]), b.env_seed(int(e)))
+            assert want["T"] >= T
+            assert np.array_equal(km[:, e, 0].cpu().numpy(), want["k"][:T]) and np.array_equal(km[:, e, 1].cpu().numpy(), want["m"][:T])
+            assert np.array_equal(H.bits(rw[:, e].cpu().numpy()), H.bits(want["reward"][:T]))
+    # rewards telescope: minus their sum over the T steps is the tardiness accumulated so far (no episode has ended yet)
+    assert torch.equal((-rw_w.sum(0)).to(torch.int64), fin_w["delay_time_sum"])
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_steps_without_a_state_do_not_change_later_states(torch_gpu, variant):
     """fjsp_env_step with d_state == NULL skips the observation; the next step that returns a state rebuilds
