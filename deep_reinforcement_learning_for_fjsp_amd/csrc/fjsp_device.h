@@ -96,6 +96,9 @@ struct Layout {
     // 16 x double2 {fluid_rate_sum, fluid_time_sum}: two 16-byte loads per lane and slot  [written by fluid_tables_kernel];
     // behind the four slots one line of per-lane words (machine / job / instance: fjsp_env.hip) and the jobs' due dates
     uint32_t i_op;
+    // ... and the {arrival, rate} table once more MACHINE-major, f64[MP][64][2]: Machine.gap_ave reads whole machines, and in
+    // large batches only the candidate ones (fjsp_group.hip g_gap_ave_lean: 5 lines per candidate instead of the whole table)
+    uint32_t i_colm;
     // env record: EnvScalars at 0
     uint32_t e_stride;
     uint32_t e_tend;    // i32[MP]  machine.time_end
@@ -154,6 +157,8 @@ struct DevBatch {
     int32_t grp;             // 1 = the batch fits the group kernels (fjsp_group.hip): one job per kind, one order, <= 64 operation
                              // types, <= 8 machines, <= 15 jobs, SO_FJSSP or MO_FJSSP_discretes
     int32_t kmax;            // operation types of the largest instance
+    const uint8_t *kenv;     // row-kernel batches: operation types of the instance every environment plays, u8[N] (the large-batch
+                             // kernels read it first and request no operation rows beyond it)
     uint32_t *pending_count; // [0] number of envs parked at an order arrival by the last launch, [1 + slot] their env ids
     uint16_t *lp_in;         // [slot][2][KP] LP inputs (Q, n_now) of the parked env in that slot (written when it parks)
     double *lp_x;            // [slot][KP][MP] fluid solution of that LP (uploaded by the host service, read by arrival_kernel)

@@ -397,6 +397,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             L.i_bk = take((size_t)Bmax * 8, 8);
         }
         L.i_op = b.grp ? take(2048 + 128, 256) : 0u;
+        L.i_colm = b.grp ? take(MP * 64 * 16, 128) : 0u;
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(b.single_job ? 8 : MP * KP * 8, 8); L.e_asg = take(KP, 4);
@@ -582,6 +583,15 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         }
         b.inst = reinterpret_cast<unsigned char *>(pi);
         b.envs = reinterpret_cast<unsigned char *>(pe);
+        b.kenv = nullptr;
+        if (b.grp) {       // operation types of every environment's instance (fjsp_group.hip: large-batch kernels)
+            std::vector<uint8_t> kq(N);
+            for (size_t q = 0; q < N; ++q) kq[q] = (uint8_t)s->v[(size_t)first + (NI == N ? q : q % NI)].K;
+            void *pk = nullptr;
+            if (!hip_ok(hipMalloc(&pk, N), "hipMalloc K table") || (e->allocs.push_back(pk), false) ||
+                !hip_ok(hipMemcpy(pk, kq.data(), N, hipMemcpyHostToDevice), "upload K table")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
+            b.kenv = reinterpret_cast<const uint8_t *>(pk);
+        }
         // every env starts done so that step() before reset() is flagged, like the
         // reference's uninitialised object would fail
         std::vector<unsigned char> eslab(N * L.e_stride, 0);

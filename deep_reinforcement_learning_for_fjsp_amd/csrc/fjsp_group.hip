@@ -319,19 +319,19 @@ GDEV double g_walk(const GE<V> &e, bool walk, int row) {
     return sm;
 }
 
-// Request the {arrival, rate} rows of every slot of the rows with `need` (class_FJSSP.py:144-146 reads all of them)
+// Request the {arrival, rate} entries of every slot of the rows with `need`, for the IDLE machines (every candidate list of
+// machine_select is a subset of them), from the machine-major copy of the table (Layout::i_colm): class_FJSSP.py:144-146 reads a
+// whole machine at a time
 template <int V, int MPC>
 GDEV void g_cols_issue(const GE<V> &e, const DevBatch &b, bool need, GCols<MPC> &cr) {
-    const double2 *col = reinterpret_cast<const double2 *>(e.ir + b.L.i_col);
+    const double2 *colm = reinterpret_cast<const double2 *>(e.ir + b.L.i_colm);
+    const uint32_t idle = need ? (~e.busy & e.mmask) : 0u;
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
 #pragma unroll
-        for (int m = 0; m < MPC; ++m) cr.c[s][m] = make_double2(0.0, 0.0);
-        if (SLOT_ON(e, s) && need) {
-            const double2 *rowk = col + (16 * s + e.l) * e.MP;
-#pragma unroll
-            for (int m = 0; m < MPC; ++m)
-                if (m < e.MP) cr.c[s][m] = rowk[m];
+        for (int m = 0; m < MPC; ++m) {
+            cr.c[s][m] = make_double2(0.0, 0.0);
+            if (SLOT_ON(e, s) && ((idle >> m) & 1u)) cr.c[s][m] = colm[m * 64 + 16 * s + e.l];
         }
     }
 }
@@ -366,7 +366,7 @@ GDEV void g_gap_rows(const GE<V> &e, bool need, const GCols<MPC> &cr) {
 template <int V>
 GDEV double g_gap_ave_lean(const GE<V> &e, const DevBatch &b, bool need, uint32_t C) {
     const double dt = (double)e.t;
-    const double2 *col = reinterpret_cast<const double2 *>(e.ir + b.L.i_col);
+    const double2 *colm = reinterpret_cast<const double2 *>(e.ir + b.L.i_colm);          // machine-major: [m][64]
     uint32_t rest = need ? C : 0u;
     double sum_m = 0.0;
     while (wave_any(rest != 0)) {
@@ -377,11 +377,11 @@ GDEV double g_gap_ave_lean(const GE<V> &e, const DevBatch &b, bool need, uint32_
         for (int s = 0; s < GS; ++s) {
             if (SLOT_ON(e, s) && rest != 0) {
                 const int asg = (int)((e.asgw >> (8 * s)) & 0xFFu);
-                const double2 *rowk = col + (16 * s + e.l) * e.MP;
-                double *dst = e.rows + 16 * s + e.l;
+                const int k = 16 * s + e.l;
+                double *dst = e.rows + k;
                 // (entries of types that cannot run on the machine hold arrival = rate = 0: their gap is +0.0, see g_gap_rows)
-                const double2 a0 = rowk[m0 & 7];
-                const double2 a1 = m1 < 8 ? rowk[m1] : make_double2(0.0, 0.0), a2 = m2 < 8 ? rowk[m2] : make_double2(0.0, 0.0);
+                const double2 a0 = colm[(m0 & 7) * 64 + k];
+                const double2 a1 = m1 < 8 ? colm[m1 * 64 + k] : make_double2(0.0, 0.0), a2 = m2 < 8 ? colm[m2 * 64 + k] : make_double2(0.0, 0.0);
                 dst[0] = (asg == m0 ? a0.x - 1.0 : a0.x) - (a0.x - dt * a0.y);          // class_FJSSP.py:198, :304, :137-142
                 dst[KS] = (asg == m1 ? a1.x - 1.0 : a1.x) - (a1.x - dt * a1.y);
                 dst[2 * KS] = (asg == m2 ? a2.x - 1.0 : a2.x) - (a2.x - dt * a2.y);
@@ -554,7 +554,7 @@ GDEV double g_observe(const GE<V> &e, const DevBatch &b, bool on, bool stats_onl
         rt[s] = make_double2(e.rsum[s], e.tsum[s]);
         if (!EARLY) {       // (large batches: the fluid numbers are fetched again, see g_gather_current)
             rt[s] = make_double2(0.0, 0.0);
-            if (SLOT_ON(e, s) && 16 * s + e.l < b.kmax) rt[s] = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + s * 512 + 256)[e.l];
+            if (SLOT_ON(e, s) && 16 * s + e.l < e.K) rt[s] = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + s * 512 + 256)[e.l];
         }
     }
 #pragma unroll
@@ -685,7 +685,10 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
     unsigned char *er = b.envs + (size_t)e.env * FO::e_stride_plain((uint32_t)MP, (uint32_t)JP, 64u, true);
     e.ir = ir; e.er = er;
     e.rows = reinterpret_cast<double *>(lds) + (size_t)(lane >> 4) * rows_per_env * KS;
-    // ---- issue every load
+    // ---- issue every load.  Operation rows: up to the batch's largest instance (small batches: one round trip), or up to
+    // THIS environment's operation count, fetched first (large batches: a dependent fetch of one byte buys 2-4 lines of padding)
+    int kq = b.kmax;
+    if (!EARLY) kq = (int)b.kenv[e.env];
     const unsigned char *op = ir + b.L.i_op;
     const uint32_t hw = reinterpret_cast<const uint32_t *>(op + 2048)[e.l];        // machine / job / instance words
     const int duej = reinterpret_cast<const int32_t *>(op + 2048 + 64)[e.l];
@@ -694,7 +697,7 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
         A[s] = make_uint4(0u, 0u, 0u, 0u); B[s] = make_double2(0.0, 0.0);
-        if (16 * s + e.l < b.kmax) {
+        if (16 * s + e.l < kq) {
             const unsigned char *slot = op + s * 512;
             A[s] = reinterpret_cast<const uint4 *>(slot)[e.l];
             if (EARLY) B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];      // (large batches: g_gather_current, g_observe)
@@ -882,7 +885,7 @@ GDEV bool rule_wants_gap_ave(uint32_t araw) {
 // EARLY: request the gap_ave rows together with the state (small batches: a wave is alone on its SIMD and nothing else hides
 // the memory round trip); otherwise they are fetched where they are used and the kernel keeps to 128 registers
 template <int V, int MPC, bool EARLY>
-__global__ __launch_bounds__(64, EARLY ? 1 : (V == FJSP_VARIANT_MO_FJSSP_DISCRETES ? 3 : 4)) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
+__global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
                                                    double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     GE<V> e;
     GSTAMP_DECL;
@@ -899,10 +902,8 @@ __global__ __launch_bounds__(64, EARLY ? 1 : (V == FJSP_VARIANT_MO_FJSSP_DISCRET
     }
     GCols<MPC> cr;
     bool gap_need = false;
-    g_open<V, EARLY>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), [&]() __attribute__((always_inline)) {
-        gap_need = env_raw < b.N && rule_wants_gap_ave<V>(araw);
-        if (EARLY) g_cols_issue<V, MPC>(e, b, gap_need, cr);
-    });
+    g_open<V, EARLY>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), []() {});
+    gap_need = env_raw < b.N && rule_wants_gap_ave<V>(araw);
     const int a0 = (int)(araw & 0xFFu), a1 = (int)(araw >> 8);
     bool go = e.live;
     GSTAMP(0);
@@ -916,6 +917,8 @@ __global__ __launch_bounds__(64, EARLY ? 1 : (V == FJSP_VARIANT_MO_FJSSP_DISCRET
     }
     int k_sel = -1, m_sel = -1;
     GSTAMP(1);
+    // small batches: Machine.gap_ave's operands are requested now (the machines that are idle are known), used after task_select
+    if (EARLY && wave_any(gap_need && go)) g_cols_issue<V, MPC>(e, b, gap_need && go, cr);
     const double reward = g_step<V, MPC, EARLY>(e, b, go, a0, a1, mw, state_out != nullptr, state_out, gap_need && go, cr, &k_sel, &m_sel GSTAMP_ARG);
     if (e.live && e.l == 0) {
         if (reward_out) reward_out[e.env] = reward;

@@ -1571,6 +1571,7 @@ __global__ void fluid_tables_kernel(DevBatch b) {
         double a = 0.0;
         if (valid && p[m] > 0) a = (q0 * col[2 * m + 1]) / s;               // :300-302
         col[2 * m] = a;
+        if (b.grp) inst_ptr<double2>(b, inst, b.L.i_colm)[m * 64 + k] = make_double2(a, col[2 * m + 1]);      // machine-major copy
     }
     if (b.grp) {
         // the packed copy the group kernels load (Layout::i_op); one job per kind: job index == kind index
