@@ -8,6 +8,8 @@ on the host.
 """
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _capi
@@ -113,6 +115,8 @@ class EnvBatch(object):
         self.step_bytes = int(self._lib.fjsp_env_step_bytes(self._h))
         # 1: stepped by the 16-lane-row kernels (csrc/fjsp_group.hip), 0: one wavefront per environment
         self.kernel_family = int(self._lib.fjsp_env_kernel_family(self._h))
+        # 1: the fluid LPs of order arrivals are solved on the device (csrc/fjsp_lp_device.hip), 0: on the host
+        self.lp_on_device = int(self._lib.fjsp_env_lp_on_device(self._h))
         f64 = dict(dtype=torch.float64, device=self.device)
         self.state = torch.zeros(self.N, self.state_size, **f64)
         self.reward = torch.zeros(self.N, **f64)
@@ -194,6 +198,15 @@ class EnvBatch(object):
         if rc < 0:
             check(rc)
         return state_out, reward_out, done_out
+
+    def lp_device_solve(self, env, Q, n_now):
+        """Test hook (fjsp_env_lp_device_solve): the device LP solver on one LP of env's instance; returns x[K, M] (numpy)."""
+        Q = np.ascontiguousarray(Q, dtype=np.int32); n_now = np.ascontiguousarray(n_now, dtype=np.int32)
+        K = Q.shape[0]
+        x = np.zeros(K * 64, np.float64)
+        check(self._lib.fjsp_env_lp_device_solve(self._h, int(env), Q.ctypes.data_as(C.c_void_p), n_now.ctypes.data_as(C.c_void_p),
+                                                 x.ctypes.data_as(C.c_void_p)))
+        return x
 
     def step_async(self, actions, autoreset=False, mo=None):
         """fjsp_env_step_async: like step(), but envs that reach an order arrival park (their fluid LP is solved by

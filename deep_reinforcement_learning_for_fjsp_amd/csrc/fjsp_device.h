@@ -195,7 +195,12 @@ int launch_rollout(const DevBatch &b, const uint8_t *actions, const double *mo, 
 // multi-order: resume the envs whose pending LP has been solved (x in e_xin)
 // ids u32[n_pending] / x_list f64[n_pending][KP][MP]: the parked envs and their LP solutions (device)
 int launch_arrival(const DevBatch &b, const double *mo, int n_pending, const uint32_t *ids, const double *x_list, double *state,
-                   double *reward, uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready = nullptr, bool mark_resumed = false);
+                   double *reward, uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready = nullptr, bool mark_resumed = false,
+                   const uint32_t *n_dev = nullptr);     // n_dev: read the count on the device (the grid then covers the batch)
+// the order-arrival LPs on the device (fjsp_lp_device.hip): one workgroup per parked environment, x into lp_x[slot]
+size_t lp_device_lds_bytes(int K, int M, int nx, int R, int MP);
+int launch_lp_device(const DevBatch &b, const uint32_t *count_dev, int count_host, const uint32_t *ids, const uint16_t *lp_in, double *lp_x,
+                     uint32_t *err, unsigned long long *solved, size_t lds, hipStream_t st);
 // policy inside the launch (fjsp_policy.h)
 struct ActorParams;
 struct PolicyRolloutIO;

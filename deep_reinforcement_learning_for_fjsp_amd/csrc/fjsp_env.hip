@@ -83,7 +83,12 @@ struct fjsp_env {
     int64_t async_parked = 0;           // envs currently parked (host view)
     bool failed = false;        // the arrival service failed mid-step: parked envs are in limbo, the handle refuses further steps
     int lp_threads = 0;         // 0 = default (min(host cores, 16))
-    int64_t lp_solves = 0;      // order-arrival LPs solved so far
+    int64_t lp_solves = 0;      // order-arrival LPs solved so far (host service)
+    // device LP service (fjsp_lp_device.hip): chosen at create time when the largest tableau of the batch fits the CU's LDS
+    bool lp_device = false;
+    size_t lp_lds = 0;
+    uint32_t *d_lp_err = nullptr;                // [0] nonzero: an LP failed on the device (reported at the next synchronising call)
+    unsigned long long *d_lp_solved = nullptr;   // LPs solved on the device so far
     struct LpPool *pool = nullptr;
 };
 
@@ -580,6 +585,26 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             }
             b.lp_in = reinterpret_cast<uint16_t *>(pin);
             b.lp_x = reinterpret_cast<double *>(px);
+            // the LPs of order arrivals on the device when every tableau this batch can meet fits the LDS of a CU
+            // (FJSP_LP_IMPL=host keeps the host simplex: A/B runs, and the parity test of the two)
+            size_t lds_max = 0;
+            for (size_t i = 0; i < NI; ++i) {
+                const Instance &in = s->v[(size_t)first + i];
+                int nx = 0;
+                for (int v : in.p) nx += v > 0 ? 1 : 0;
+                lds_max = std::max(lds_max, lp_device_lds_bytes(in.K, in.M, nx, in.R, b.MP));
+            }
+            const char *impl = getenv("FJSP_LP_IMPL");
+            if (lds_max <= 156 * 1024 && !(impl && strcmp(impl, "host") == 0)) {
+                void *pe2 = nullptr, *ps2 = nullptr;
+                if (!hip_ok(hipMalloc(&pe2, 8), "hipMalloc LP error word") || (e->allocs.push_back(pe2), false) ||
+                    !hip_ok(hipMalloc(&ps2, 8), "hipMalloc LP counter") || (e->allocs.push_back(ps2), false) ||
+                    !hip_ok(hipMemset(pe2, 0, 8), "hipMemset") || !hip_ok(hipMemset(ps2, 0, 8), "hipMemset")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
+                e->d_lp_err = reinterpret_cast<uint32_t *>(pe2);
+                e->d_lp_solved = reinterpret_cast<unsigned long long *>(ps2);
+                e->lp_device = true;
+                e->lp_lds = lds_max;
+            }
         }
         b.inst = reinterpret_cast<unsigned char *>(pi);
         b.envs = reinterpret_cast<unsigned char *>(pe);
@@ -656,7 +681,43 @@ int fjsp_env_state_size(const fjsp_env *e) { return e ? e->b.state_size : 0; }
 int fjsp_env_device(const fjsp_env *e) { return e ? e->device : -1; }
 int64_t fjsp_env_step_bytes(const fjsp_env *e) { return e ? e->step_bytes : 0; }
 int fjsp_env_kernel_family(const fjsp_env *e) { return e ? e->b.grp : 0; }
-int64_t fjsp_env_lp_solves(const fjsp_env *e) { return e ? e->lp_solves : 0; }
+int64_t fjsp_env_lp_solves(const fjsp_env *e) {
+    if (!e) return 0;
+    int64_t n = e->lp_solves;
+    if (e->lp_device) {        // (synchronises: the counter lives on the device)
+        DeviceGuard guard(e->device);
+        unsigned long long dev = 0;
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&dev, e->d_lp_solved, 8, hipMemcpyDeviceToHost) == hipSuccess) n += (int64_t)dev;
+    }
+    return n;
+}
+int fjsp_env_lp_on_device(const fjsp_env *e) { return (e && e->lp_device) ? 1 : 0; }
+int fjsp_env_lp_device_solve(fjsp_env *e, int32_t env, const int32_t *Q, const int32_t *n_now, double *x) {
+    if (!e || !Q || !n_now || !x || env < 0 || env >= e->b.N) { set_error("fjsp_env_lp_device_solve: bad arguments"); return FJSP_E_ARG; }
+    if (!e->lp_device) { set_error("fjsp_env_lp_device_solve: this batch keeps the host LP service"); return FJSP_E_UNSUPPORTED; }
+    DeviceGuard guard(e->device);
+    const DevBatch &b = e->b;
+    const Instance &in = e->src->v[(size_t)e->first + (size_t)(env % b.n_inst)];
+    std::vector<uint16_t> lpq((size_t)2 * b.KP, 0);
+    for (int k = 0; k < in.K; ++k) { lpq[(size_t)k] = (uint16_t)Q[k]; lpq[(size_t)b.KP + k] = (uint16_t)n_now[k]; }
+    const uint32_t id = (uint32_t)env;
+    // (slot 0 of the staging arrays; the batch must be idle: no parked environments)
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(b.lp_in, lpq.data(), lpq.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b.pending_count + 1, &id, 4, hipMemcpyHostToDevice));
+    if (launch_lp_device(b, nullptr, 1, b.pending_count + 1, b.lp_in, b.lp_x, e->d_lp_err, nullptr, e->lp_lds, nullptr) != 0) {
+        set_error("lp_device_kernel launch failed"); return FJSP_E_HIP;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, e->d_lp_err, 4, hipMemcpyDeviceToHost));
+    if (err) { const uint32_t z = 0; (void)hipMemcpy(e->d_lp_err, &z, 4, hipMemcpyHostToDevice); set_error("fluid LP failed on the device (code " + std::to_string(err) + ")"); return FJSP_E_LP; }
+    std::vector<double> xs((size_t)b.KP * b.MP);
+    HIP_TRY(hipMemcpy(xs.data(), b.lp_x, xs.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < in.K; ++k)
+        for (int m = 0; m < in.M; ++m) x[(size_t)k * in.M + m] = xs[(size_t)k * b.MP + m];
+    return FJSP_OK;
+}
 int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads) {
     if (!e || n_threads < 0) { set_error("fjsp_env_set_lp_threads: bad arguments"); return FJSP_E_ARG; }
     e->lp_threads = n_threads;
@@ -686,6 +747,18 @@ int service_arrivals(fjsp_env *e, const double *d_mo, double *d_state, double *d
 int service_arrivals_impl(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done, int16_t *d_trace,
                           hipStream_t st) {
     const DevBatch &b = e->b;
+    if (e->lp_device) {
+        // the whole service on the stream: LP kernel (one workgroup per parked env, count read on the device), arrival_kernel,
+        // pending list emptied -- no host round trip, fjsp_env_step stays asynchronous
+        if (launch_lp_device(b, b.pending_count, 0, b.pending_count + 1, b.lp_in, b.lp_x, e->d_lp_err, e->d_lp_solved, e->lp_lds, st) != 0) {
+            set_error("lp_device_kernel launch failed"); return FJSP_E_HIP;
+        }
+        if (launch_arrival(b, d_mo, 0, b.pending_count + 1, b.lp_x, d_state, d_reward, d_done, d_trace, st, nullptr, false, b.pending_count) != 0) {
+            set_error("arrival_kernel launch failed"); return FJSP_E_HIP;
+        }
+        HIP_TRY(hipMemsetAsync(b.pending_count, 0, 4, st));
+        return FJSP_OK;
+    }
     // (the sync below also orders this call after the previous call's solution upload, so the pinned staging
     // buffers are free again)
     HIP_TRY(hipMemcpyAsync(e->h_pending, b.pending_count, 4, hipMemcpyDeviceToHost, st));
@@ -1069,6 +1142,12 @@ int fjsp_env_read(fjsp_env *e, int64_t *d_delay_time_sum, int32_t *d_makespan, i
     DeviceGuard guard(e->device);
     if (launch_read(e->b, d_delay_time_sum, d_makespan, d_completion, d_step_time, d_step_count, d_done, d_status,
                     (hipStream_t)stream) != 0) { set_error("read_kernel launch failed"); return FJSP_E_HIP; }
+    if (e->lp_device) {        // a failed device LP surfaces here (read-back is where callers synchronise anyway)
+        uint32_t err = 0;
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(&err, e->d_lp_err, 4, hipMemcpyDeviceToHost));
+        if (err) { e->failed = true; set_error("an order-arrival LP failed on the device (code " + std::to_string(err) + "); the batch is unusable: destroy it"); return FJSP_E_LP; }
+    }
     return FJSP_OK;
 }
 

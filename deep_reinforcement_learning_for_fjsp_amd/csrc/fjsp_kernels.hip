@@ -1855,9 +1855,11 @@ __global__ __launch_bounds__(1024) void rollout_policy_kernel(DevBatch b, ActorP
 template <int KC, int V>
 __global__ __launch_bounds__(256, KC >= 4 ? 2 : 4) void arrival_kernel(DevBatch b, const double *mo, int n_pending, const uint32_t *ids, const double *x_list,
                                                          double *state_out, double *reward_out, uint8_t *done_out, int16_t *trace_km,
-                                                         uint8_t *ready, int mark_resumed) {
+                                                         uint8_t *ready, int mark_resumed, const uint32_t *n_dev) {
     const int wave = uni((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * (blockDim.x >> 6) + wave;
+    // (device LP service: the number of parked environments never visits the host; the grid covers the whole batch)
+    if (n_dev) n_pending = (int)min(*n_dev, (uint32_t)b.N);
     if (idx >= n_pending) return;
     const int env = (int)ids[idx];
     W<KC, V> w;
@@ -2039,13 +2041,13 @@ int launch_rollout_policy(const DevBatch &b, const ActorParams &ap, const Policy
 }
 
 int launch_arrival(const DevBatch &b, const double *mo, int n_pending, const uint32_t *ids, const double *x_list, double *state,
-                   double *reward, uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready, bool mark_resumed) {
+                   double *reward, uint8_t *done, int16_t *trace_km, hipStream_t st, uint8_t *ready, bool mark_resumed, const uint32_t *n_dev) {
     const size_t lds = step_lds_bytes(b);
-    const dim3 grid((unsigned)((n_pending + 3) / 4));
+    const dim3 grid((unsigned)(((n_dev ? b.N : n_pending) + 3) / 4));
     auto go = [&](auto kc, auto v) {
         allow_lds(&arrival_kernel<decltype(kc)::value, decltype(v)::value>, lds);
         hipLaunchKernelGGL((arrival_kernel<decltype(kc)::value, decltype(v)::value>), grid, dim3(256), lds, st, b, mo,
-                           n_pending, ids, x_list, state, reward, done, trace_km, ready, mark_resumed ? 1 : 0);
+                           n_pending, ids, x_list, state, reward, done, trace_km, ready, mark_resumed ? 1 : 0, n_dev);
     };
     const int rc = b.variant == FJSP_VARIANT_MO_DFJSP ? dispatch_kc<kDyn>(b.KC, go) : dispatch_kc<kMord>(b.KC, go);
     if (rc != 0) return -1;

@@ -246,6 +246,14 @@ int fjsp_env_kernel_family(const fjsp_env *e);
  * over n_threads host threads (0 = default: min(host cores, 16)).  fjsp_env_lp_solves: LPs solved so far. */
 int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads);
 int64_t fjsp_env_lp_solves(const fjsp_env *e);
+/* Where the order-arrival LPs of this batch are solved: 1 = on the device (csrc/fjsp_lp_device.hip: the host simplex of
+ * csrc/fjsp_lp.cpp restated pivot for pivot, one workgroup per parked environment, tableau in LDS; chosen at create time when
+ * the largest tableau of the batch fits a CU's LDS; fjsp_env_step then never synchronises), 0 = on the host.  Same x either
+ * way, bit for bit.  FJSP_LP_IMPL=host at create time forces 0.
+ * fjsp_env_lp_device_solve (test hook): the device solver on one LP of env's instance -- Q[K], n_now[K] as
+ * class_FJSSP.py:234-237 builds them -- x f64[K*M] (k-major) to the host; the batch must have no parked environments. */
+int fjsp_env_lp_on_device(const fjsp_env *e);
+int fjsp_env_lp_device_solve(fjsp_env *e, int32_t env, const int32_t *Q, const int32_t *n_now, double *x);
 
 /* ------------------------------------------------------------------------- *
  * Rollout buffer (on-policy Replay_Buffer, agents/MPPPO/Buffer.py:7-58) in HBM

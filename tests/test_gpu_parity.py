@@ -915,3 +915,92 @@ def test_async_arrival_service_keeps_every_env_on_its_own_trajectory(torch_gpu):
     assert refused
     c.flush_arrivals(mo)
     c.step(acts[0], mo=mo)
+
+
+def test_device_lp_equals_the_host_lp(torch_gpu):
+    """csrc/fjsp_lp_device.hip restates the host simplex (csrc/fjsp_lp.cpp) pivot for pivot: on every instance of the
+    mo_dfjsp / multiorder suites whose tableau fits the LDS, for the reset-time LP and for random live states (jobs spread
+    over the stages, so precedence rows come and go with n_now == 0), the device's x equals the host's BIT FOR BIT."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd import instances as fi
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, VARIANT_MO_DFJSP
+    rs = np.random.RandomState(17)
+    checked = 0
+    for suite, variant in (("mo_dfjsp", VARIANT_MO_DFJSP), ("multiorder", 0)):
+        insts, _, _ = H.load_suite(suite)
+        for i, a in enumerate(insts):
+            s = H.instance_set_from([a])
+            b = EnvBatch(s, 4, variant=variant, rng_seed=1)
+            if not b.lp_on_device:
+                continue                                   # (tableau beyond the LDS: this batch keeps the host service)
+            koff = np.concatenate([[0], np.cumsum(a.Jr)])
+            K, M = a.p.shape
+            for trial in range(6):
+                Q = np.zeros(K, np.int32); now = np.zeros(K, np.int32)
+                for r in range(len(a.Jr)):
+                    n = int(rs.randint(1, 25))
+                    if trial == 0:
+                        stages = np.zeros(n, np.int64)                             # every job at stage 0: the reset-time LP
+                    else:
+                        stages = rs.randint(0, a.Jr[r], n)                          # jobs spread over the stages (one stays at the last)
+                        stages[0] = a.Jr[r] - 1 if trial % 2 else stages[0]
+                    for j in range(a.Jr[r]):
+                        Q[koff[r] + j] = max(1, int((stages <= j).sum()))           # tasks of (r, j) still unprocessed (class_FJSSP.py:234-235)
+                        now[koff[r] + j] = int((stages == j).sum())                 # jobs waiting at (r, j)                 (:236-237)
+                want, _ = fi.fluid_lp(a.Jr, a.p, Q, now)
+                got = b.lp_device_solve(trial % 4, Q, now)[:K * M].reshape(K, M)
+                assert np.array_equal(H.bits(got), H.bits(want)), "%s instance %d (%s) trial %d" % (suite, i, a.name, trial)
+                checked += 1
+    assert checked >= 12
+
+
+def test_device_lp_service_leaves_every_trajectory_unchanged(torch_gpu):
+    """The dynamic environment with its order-arrival LPs on the device against the same batch with FJSP_LP_IMPL=host:
+    rewards step by step, final makespan / tardiness / energy and the number of LPs are identical."""
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.batch import EnvBatch, VARIANT_MO_DFJSP, global_actions
+    insts, _, _ = H.load_suite("mo_dfjsp")
+
+    def tableau_bytes(a):        # rows x columns of the largest tableau of the instance (csrc/fjsp_lp_device.hip lp_device_lds_bytes)
+        K, M = a.p.shape
+        nr = K + M + (K - len(a.Jr))
+        return nr * (int((a.p > 0).sum()) + 1 + nr + 1) * 8
+    insts = [a for a in insts if tableau_bytes(a) < 130 * 1024]      # (the industrial folders and the generated ones; not data/HMPSAC)
+    assert len(insts) >= 4
+    s = H.instance_set_from(insts)
+    N, T = 96, 1600
+    acts = torch.from_numpy(global_actions(29, 0, N, T, 12, 10)).cuda()
+    mo = torch.zeros(N, 4, dtype=torch.float64, device="cuda"); mo[:, 0] = 1.0
+
+    def play(impl):
+        old = os.environ.get("FJSP_LP_IMPL")
+        if impl:
+            os.environ["FJSP_LP_IMPL"] = impl
+        try:
+            b = EnvBatch(s, N, variant=VARIANT_MO_DFJSP, rng_seed=5)
+        finally:
+            if impl:
+                if old is None:
+                    del os.environ["FJSP_LP_IMPL"]
+                else:
+                    os.environ["FJSP_LP_IMPL"] = old
+        b.reset()
+        rew = torch.zeros(T, N, dtype=torch.float64, device="cuda")
+        for t in range(T):
+            live = b.done == 0
+            _, r, d = b.step(acts[t], mo=mo)
+            rew[t] = torch.where(live, r, torch.zeros_like(r))
+            if t % 50 == 49 and bool((b.done != 0).all()):
+                break
+        return b, rew, b.read()
+
+    dev, rew_d, fin_d = play(None)
+    host, rew_h, fin_h = play("host")
+    if not dev.lp_on_device:
+        pytest.skip("the suite's largest tableau does not fit the LDS")
+    assert host.lp_on_device == 0
+    assert bool((fin_d["done"] != 0).all())
+    assert torch.equal(rew_d, rew_h)
+    for k in ("delay_time_sum", "makespan", "completion_time", "step_count", "energy_consumption", "done", "status"):
+        assert torch.equal(fin_d[k], fin_h[k]), k
+    assert dev.lp_solves == host.lp_solves > 0

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lp-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--instances", choices=["all", "industrial"], default="all",
+                    help="industrial: only data/industrial (K 31, M 20) -- every order-arrival LP fits a CU's LDS and is solved on the device")
     ap.add_argument("--blocking", action="store_true", help="fjsp_env_step (every call waits for its order-arrival LPs) instead of "
                                                             "the asynchronous arrival service (parked envs wait, the others step)")
     args = ap.parse_args()
@@ -37,6 +39,8 @@ def main():
 
     insts, _, _ = H.load_suite("mo_dfjsp")
     insts = [a for a in insts if not a.name.startswith("gen")]
+    if args.instances == "industrial":
+        insts = [a for a in insts if a.name.startswith("industrial")]
     s = H.instance_set_from(insts)
     N = args.envs
     env = EnvBatch(s, N, variant=VARIANT_MO_DFJSP, rng_seed=77)
@@ -102,7 +106,8 @@ def main():
                                "policy, per-step kernel + host LP service at order arrivals" % N,
                    "arrival_service": "blocking (fjsp_env_step)" if args.blocking else "asynchronous (fjsp_env_step_async)",
                    "env_steps_completed": env_steps,
-                   "instances": [a.name for a in insts], "lp_threads": min(args.lp_threads or 16, os.cpu_count() or 1)},
+                   "instances": [a.name for a in insts], "lp_threads": min(args.lp_threads or 16, os.cpu_count() or 1),
+                   "lp_on_device": int(env.lp_on_device)},
         "order_arrival_lps": lps, "lps_per_step": lps / args.steps, "lp_cache_hits_total": env.lp_cache_hits, "cpu_baseline": cpu}))
 
 
