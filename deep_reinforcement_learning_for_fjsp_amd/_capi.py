@@ -67,6 +67,7 @@ SIGNATURES = {
     "fjsp_env_set_lp_threads": (C.c_int, [_vp, _i32]),
     "fjsp_env_lp_solves": (_i64, [_vp]),
     "fjsp_env_lp_on_device": (_i32, [_vp]),
+    "fjsp_env_lp_device_pivots": (_i64, [_vp]),
     "fjsp_env_lp_device_solve": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "fjsp_pyset_and_order": (C.c_int, [C.c_uint32, _vp, _i32, _i32, _vp]),
     "fjsp_rollout_create": (C.c_int, [_i32, _i32, _i32, _i32, _pp]),

@@ -153,10 +153,14 @@ class FusedMLP(object):
         key = ("pass", n)
         b = self._buf.get(key)
         if b is None:
-            groups = self._lib.fjsp_mlp_train_groups(n)
+            with torch.cuda.device(self.device):                 # (the group count is the CU count of the parameters' device)
+                groups = self._lib.fjsp_mlp_train_groups(n)
             f = dict(dtype=torch.float32, device=self.device)
             b = dict(groups=groups, partial=torch.empty(groups, self.numel, **f), loss_partial=torch.empty(groups, **f), loss=torch.zeros(1, **f),
                      sumsq=torch.zeros((self.numel + 63) // 64, **f))
+            # keep the two most recent sample counts only (a partial buffer is groups x numel floats, ~20 MB per network)
+            for old_key in [k for k in self._buf if isinstance(k, tuple) and k[0] == "pass"][:-1]:
+                del self._buf[old_key]
             self._buf[key] = b
         return b
 

@@ -211,7 +211,10 @@ class EnvBatch(object):
     def step_async(self, actions, autoreset=False, mo=None):
         """fjsp_env_step_async: like step(), but envs that reach an order arrival park (their fluid LP is solved by
         host threads in the background) while the others keep stepping.  Returns (state, reward, done, ready):
-        ready[i] = 1 where this call completed a step of env i; a parked env ignored its action -- present it again.
+        ready[i] = 1 where this call completed a step of env i.  The action a parked step applies is the one of the
+        call in which the env parked (the first ready = 0): that call ran the step up to the arrival.  While the env
+        stays parked, and in the call where it comes back with ready = 1, its entry of `actions` is not looked at --
+        pair the returned row with the (state, action) of the parking call.
         Call flush_arrivals() before read() / reset() / step() / rollout()."""
         actions = _as_input("actions", actions, (self.N, 2), torch.uint8, self.device)
         if actions.data_ptr() & 1:
@@ -283,6 +286,11 @@ class EnvBatch(object):
     @property
     def lp_solves(self):
         return int(self._lib.fjsp_env_lp_solves(self._h))
+
+    @property
+    def lp_device_pivots(self):
+        """Simplex pivots executed by the device LP service so far (0 with the host service)."""
+        return int(self._lib.fjsp_env_lp_device_pivots(self._h))
 
     def machine_time_end(self):
         d = self.instances.dims(self.first)

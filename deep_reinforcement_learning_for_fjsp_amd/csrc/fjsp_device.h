@@ -199,6 +199,7 @@ int launch_arrival(const DevBatch &b, const double *mo, int n_pending, const uin
                    const uint32_t *n_dev = nullptr);     // n_dev: read the count on the device (the grid then covers the batch)
 // the order-arrival LPs on the device (fjsp_lp_device.hip): one workgroup per parked environment, x into lp_x[slot]
 size_t lp_device_lds_bytes(int K, int M, int nx, int R, int MP);
+int lp_device_max_columns();      // widest tableau the device simplex takes (its objective row lives in registers)
 int launch_lp_device(const DevBatch &b, const uint32_t *count_dev, int count_host, const uint32_t *ids, const uint16_t *lp_in, double *lp_x,
                      uint32_t *err, unsigned long long *solved, size_t lds, hipStream_t st);
 // policy inside the launch (fjsp_policy.h)

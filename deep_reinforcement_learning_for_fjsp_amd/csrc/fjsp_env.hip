@@ -49,9 +49,14 @@ struct LpCache {
         ++hits; x = it->second;
         return true;
     }
+    // bounded by bytes (keys + solutions; 256 MiB): a full memo stops taking entries -- the LPs it misses are solved
+    size_t bytes = 0;
+    static constexpr size_t kMaxBytes = (size_t)256 << 20;
     void put(const std::string &k, const std::vector<double> &x) {
         std::lock_guard<std::mutex> g(mu);
-        if (map.size() < 200000) map.emplace(k, x);
+        const size_t add = k.size() + x.size() * sizeof(double) + 64;
+        if (bytes + add > kMaxBytes) return;
+        if (map.emplace(k, x).second) bytes += add;
     }
 };
 
@@ -586,20 +591,26 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
             b.lp_in = reinterpret_cast<uint16_t *>(pin);
             b.lp_x = reinterpret_cast<double *>(px);
             // the LPs of order arrivals on the device when every tableau this batch can meet fits the LDS of a CU
-            // (FJSP_LP_IMPL=host keeps the host simplex: A/B runs, and the parity test of the two)
             size_t lds_max = 0;
             for (size_t i = 0; i < NI; ++i) {
                 const Instance &in = s->v[(size_t)first + i];
                 int nx = 0;
                 for (int v : in.p) nx += v > 0 ? 1 : 0;
                 lds_max = std::max(lds_max, lp_device_lds_bytes(in.K, in.M, nx, in.R, b.MP));
+                if (nx + 1 + (in.K + in.M + in.K - in.R) + 1 > lp_device_max_columns()) lds_max = (size_t)1 << 30;
             }
+            // Which service: one LP takes the device ~0.3 ms (a 48-pivot tableau of the industrial instances; a host core
+            // needs ~0.05 ms) but 256 of them run at once, so the device wins when arrivals come in bursts of hundreds --
+            // measured (tools/bench_dynamic.py --instances industrial): 4096 envs 32.0 M env-steps/s against the host
+            // service's 34.9 M, 32768 envs 63.1 M against 54.2 M.  Default: the device from 16384 environments on;
+            // FJSP_LP_IMPL=device / host decides for itself (A/B runs, and the parity test of the two).
             const char *impl = getenv("FJSP_LP_IMPL");
-            if (lds_max <= 156 * 1024 && !(impl && strcmp(impl, "host") == 0)) {
+            const bool want_device = impl ? strcmp(impl, "device") == 0 : b.N >= 16384;
+            if (lds_max <= 156 * 1024 && want_device) {
                 void *pe2 = nullptr, *ps2 = nullptr;
                 if (!hip_ok(hipMalloc(&pe2, 8), "hipMalloc LP error word") || (e->allocs.push_back(pe2), false) ||
-                    !hip_ok(hipMalloc(&ps2, 8), "hipMalloc LP counter") || (e->allocs.push_back(ps2), false) ||
-                    !hip_ok(hipMemset(pe2, 0, 8), "hipMemset") || !hip_ok(hipMemset(ps2, 0, 8), "hipMemset")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
+                    !hip_ok(hipMalloc(&ps2, 16), "hipMalloc LP counters") || (e->allocs.push_back(ps2), false) ||
+                    !hip_ok(hipMemset(pe2, 0, 8), "hipMemset") || !hip_ok(hipMemset(ps2, 0, 16), "hipMemset")) { fjsp_env_destroy(e); return FJSP_E_HIP; }
                 e->d_lp_err = reinterpret_cast<uint32_t *>(pe2);
                 e->d_lp_solved = reinterpret_cast<unsigned long long *>(ps2);
                 e->lp_device = true;
@@ -692,6 +703,13 @@ int64_t fjsp_env_lp_solves(const fjsp_env *e) {
     return n;
 }
 int fjsp_env_lp_on_device(const fjsp_env *e) { return (e && e->lp_device) ? 1 : 0; }
+int64_t fjsp_env_lp_device_pivots(const fjsp_env *e) {
+    if (!e || !e->lp_device) return 0;
+    DeviceGuard guard(e->device);
+    unsigned long long dev = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&dev, e->d_lp_solved + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)dev;
+}
 int fjsp_env_lp_device_solve(fjsp_env *e, int32_t env, const int32_t *Q, const int32_t *n_now, double *x) {
     if (!e || !Q || !n_now || !x || env < 0 || env >= e->b.N) { set_error("fjsp_env_lp_device_solve: bad arguments"); return FJSP_E_ARG; }
     if (!e->lp_device) { set_error("fjsp_env_lp_device_solve: this batch keeps the host LP service"); return FJSP_E_UNSUPPORTED; }
@@ -1000,21 +1018,29 @@ int fjsp_env_step_async(fjsp_env *e, const uint8_t *d_actions, const double *d_m
             if (rc != FJSP_OK) { e->failed = true; return rc; }
         }
     }
-    if (!slot) { set_error("fjsp_env_step_async: no free batch"); return FJSP_E_STATE; }
-    HIP_TRY(hipMemsetAsync(slot->d_count, 0, 4, st));
-    DevBatch b2 = e->b;
-    b2.pending_count = slot->d_count;
-    b2.lp_in = slot->d_lp_in;
-    if (launch_step(b2, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, st, d_ready) != 0) {
-        set_error("step_kernel launch failed"); return FJSP_E_HIP;
-    }
-    const size_t KP = (size_t)e->b.KP;
-    const uint32_t head = std::min<uint32_t>(kAsyncHead, (uint32_t)e->b.N);
-    HIP_TRY(hipEventRecord(e->ev_step, st));
-    HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_step, 0));
-    HIP_TRY(hipMemcpyAsync(slot->h_ids, slot->d_count, (size_t)(1 + head) * 4, hipMemcpyDeviceToHost, e->copy_stream));
-    HIP_TRY(hipMemcpyAsync(slot->h_lp_in, slot->d_lp_in, (size_t)head * 2 * KP * 2, hipMemcpyDeviceToHost, e->copy_stream));
-    HIP_TRY(hipEventRecord(slot->ev_head, e->copy_stream));
+    if (!slot) { set_error("fjsp_env_step_async: no free batch"); e->failed = true; return FJSP_E_STATE; }
+    // From here on environments resumed by async_progress carry their solutions and the launch parks new ones into
+    // `slot`: an error on the way leaves them without a path back, so every failing exit marks the batch unusable
+    // (as service_arrivals does for the blocking service).
+    auto launch_and_track = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(slot->d_count, 0, 4, st));
+        DevBatch b2 = e->b;
+        b2.pending_count = slot->d_count;
+        b2.lp_in = slot->d_lp_in;
+        if (launch_step(b2, d_actions, d_mo, autoreset ? 1 : 0, d_state, d_reward, d_done, nullptr, st, d_ready) != 0) {
+            set_error("step_kernel launch failed"); return FJSP_E_HIP;
+        }
+        const size_t KP = (size_t)e->b.KP;
+        const uint32_t head = std::min<uint32_t>(kAsyncHead, (uint32_t)e->b.N);
+        HIP_TRY(hipEventRecord(e->ev_step, st));
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_step, 0));
+        HIP_TRY(hipMemcpyAsync(slot->h_ids, slot->d_count, (size_t)(1 + head) * 4, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipMemcpyAsync(slot->h_lp_in, slot->d_lp_in, (size_t)head * 2 * KP * 2, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipEventRecord(slot->ev_head, e->copy_stream));
+        return FJSP_OK;
+    };
+    rc = launch_and_track();
+    if (rc != FJSP_OK) { e->failed = true; return rc; }
     slot->state = AsyncBatch::HEAD_COPY;
     return FJSP_OK;
 }
@@ -1139,6 +1165,8 @@ int fjsp_env_rollout_policy(fjsp_env *e, fjsp_rollout *buf, const fjsp_actor_par
 int fjsp_env_read(fjsp_env *e, int64_t *d_delay_time_sum, int32_t *d_makespan, int32_t *d_completion,
                   int32_t *d_step_time, int32_t *d_step_count, uint8_t *d_done, uint32_t *d_status, void *stream) {
     if (!e) { set_error("fjsp_env_read: null env"); return FJSP_E_ARG; }
+    if (e->failed) { set_error("fjsp_env_read: the order-arrival service of this batch failed earlier; destroy the batch"); return FJSP_E_STATE; }
+    if (!async_idle(e)) { set_error("fjsp_env_read: environments are parked in the asynchronous arrival service; call fjsp_env_arrivals_flush first"); return FJSP_E_STATE; }
     DeviceGuard guard(e->device);
     if (launch_read(e->b, d_delay_time_sum, d_makespan, d_completion, d_step_time, d_step_count, d_done, d_status,
                     (hipStream_t)stream) != 0) { set_error("read_kernel launch failed"); return FJSP_E_HIP; }

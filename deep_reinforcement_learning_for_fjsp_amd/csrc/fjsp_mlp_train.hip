@@ -530,22 +530,50 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float *p, const float *
     }
 }
 
-int g_groups = 0;
-bool g_lds_ok = false;
+// per device: the workgroup count (= its CU count) and whether the kernels' dynamic-LDS limit has been raised there
+constexpr int kMaxDevices = 64;
+int g_groups[kMaxDevices] = {};
+bool g_lds_ok[kMaxDevices] = {};
+
+int groups_of_device(int dev) {
+    if (dev < 0 || dev >= kMaxDevices) return 256;
+    if (g_groups[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_groups[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_groups[dev];
+}
+
+// the device a buffer lives on (-1: not a device pointer)
+int device_of(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return at.type == hipMemoryTypeDevice ? at.device : -1;
+}
+
+struct OnDevice {          // launches below go to the parameters' device, whatever the caller's current device is
+    int prev = -1;
+    explicit OnDevice(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+    }
+    ~OnDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 }  // namespace
 
 extern "C" {
 
-int fjsp_mlp_train_groups(int32_t n) {
-    if (g_groups == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_groups = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int tiles = (n + TS - 1) / TS;
-    return tiles < g_groups ? (tiles > 0 ? tiles : 1) : g_groups;
+static int groups_for(int32_t n, int dev) {
+    const int g = groups_of_device(dev), tiles = (n + TS - 1) / TS;
+    return tiles < g ? (tiles > 0 ? tiles : 1) : g;
+}
+
+int fjsp_mlp_train_groups(int32_t n) {          // (for the caller's current device: where it allocates the buffers)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    return groups_for(n, dev);
 }
 
 namespace {
@@ -561,15 +589,18 @@ int train_pass_launch(int32_t mode, const float *d_params, const float *d_x, int
         fjsp::set_error("fjsp_mlp_train_pass: supports state_size <= 31, hidden == 128, outputs <= 32 (critic: 1)"); return FJSP_E_UNSUPPORTED;
     }
     if ((reinterpret_cast<uintptr_t>(d_params) & 15) != 0) { fjsp::set_error("fjsp_mlp_train_pass: parameter buffer must be 16-byte aligned"); return FJSP_E_ARG; }
-    const int groups = fjsp_mlp_train_groups(n);
-    if (n_groups != groups) { fjsp::set_error("fjsp_mlp_train_pass: n_groups must be fjsp_mlp_train_groups(n)"); return FJSP_E_ARG; }
+    const int dev = device_of(d_params);
+    if (dev < 0 || dev >= kMaxDevices) { fjsp::set_error("fjsp_mlp_train_pass: the parameter buffer is not device memory"); return FJSP_E_ARG; }
+    OnDevice on(dev);
+    const int groups = groups_for(n, dev);
+    if (n_groups != groups) { fjsp::set_error("fjsp_mlp_train_pass: n_groups must be fjsp_mlp_train_groups(n) taken on the parameters' device"); return FJSP_E_ARG; }
     const size_t lds = (size_t)kLdsFloats * sizeof(float);
-    if (!g_lds_ok) {
+    if (!g_lds_ok[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_train_pass_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_train_pass_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             fjsp::set_error("fjsp_mlp_train_pass: cannot raise the dynamic LDS limit"); return FJSP_E_HIP;
         }
-        g_lds_ok = true;
+        g_lds_ok[dev] = true;
     }
     PassArgs a;
     a.params = d_params; a.x = d_x; a.aux0 = d_aux0; a.aux1 = d_aux1; a.aux2 = d_aux2; a.count = d_count;

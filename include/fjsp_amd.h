@@ -191,9 +191,14 @@ int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_
  * that reaches an arrival PARKS while the rest of the batch keeps stepping: its LP inputs travel to the host, a worker
  * pool solves them, and a later call uploads the solution and finishes the parked step (arrival_kernel).
  * d_ready u8[N]: 1 = this call completed a step of env i (d_state / d_reward / d_done row i are that step's), 0 = the
- * env is parked: its row is untouched, its action was ignored -- present the same action again.  An env's own
- * trajectory is the one fjsp_env_step produces for the same action sequence (parity is per env); only the interleaving
- * across envs differs.  fjsp_env_arrivals_flush waits for every parked env and finishes its step (rows + ready = 1);
+ * env is parked and its row is untouched.  WHICH ACTION A PARKED STEP APPLIES: the one presented in the call where the
+ * env parked (the first call that returns ready = 0 for it) -- that call already ran the step up to the arrival.  Calls
+ * made while it stays parked, and the call in which it resumes (ready = 1 again), do not look at its action at all: the
+ * resumed row is the result of the action of the parking call.  A caller that records transitions must therefore keep
+ * (state, action) of the parking call and pair them with the row that comes back with ready = 1; resampling a
+ * stochastic policy for an env that shows ready = 0 has no effect on the environment.  An env's own trajectory is the
+ * one fjsp_env_step produces for the sequence of its APPLIED actions (parity is per env); only the interleaving across
+ * envs differs.  fjsp_env_arrivals_flush waits for every parked env and finishes its step (rows + ready = 1);
  * it must run before fjsp_env_step / _reset / _rollout / destroy are used on the batch again (they return
  * FJSP_E_STATE while envs are parked).  fjsp_env_parked: parked envs as last seen by the host. */
 int fjsp_env_step_async(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
@@ -247,12 +252,16 @@ int fjsp_env_kernel_family(const fjsp_env *e);
 int fjsp_env_set_lp_threads(fjsp_env *e, int32_t n_threads);
 int64_t fjsp_env_lp_solves(const fjsp_env *e);
 /* Where the order-arrival LPs of this batch are solved: 1 = on the device (csrc/fjsp_lp_device.hip: the host simplex of
- * csrc/fjsp_lp.cpp restated pivot for pivot, one workgroup per parked environment, tableau in LDS; chosen at create time when
- * the largest tableau of the batch fits a CU's LDS; fjsp_env_step then never synchronises), 0 = on the host.  Same x either
- * way, bit for bit.  FJSP_LP_IMPL=host at create time forces 0.
+ * csrc/fjsp_lp.cpp restated pivot for pivot, one workgroup per parked environment, tableau in LDS; fjsp_env_step then never
+ * synchronises), 0 = on the host.  Same x either way, bit for bit.  Chosen at create time: the device when the largest tableau
+ * of the batch fits a CU's LDS (and is at most 512 columns wide) and the batch has 16384 environments or more -- a single LP is
+ * ~6x slower on the device than on a host core, 256 run at once: below that size the host service with its cache of solved
+ * LPs is as fast or faster (DESIGN.md has the measurements).  FJSP_LP_IMPL=device / host at create time overrides the size rule.
  * fjsp_env_lp_device_solve (test hook): the device solver on one LP of env's instance -- Q[K], n_now[K] as
  * class_FJSSP.py:234-237 builds them -- x f64[K*M] (k-major) to the host; the batch must have no parked environments. */
 int fjsp_env_lp_on_device(const fjsp_env *e);
+/* Pivots the device simplex has executed so far, all LPs together (0 when the batch keeps the host service; synchronises). */
+int64_t fjsp_env_lp_device_pivots(const fjsp_env *e);
 int fjsp_env_lp_device_solve(fjsp_env *e, int32_t env, const int32_t *Q, const int32_t *n_now, double *x);
 
 /* ------------------------------------------------------------------------- *

@@ -143,3 +143,22 @@ def assert_state_close(got, want, what="", mo=False, sf=False, dyn=False):
         if c >= first_delta and (c - shift) in pw:
             atol = max(atol, 2e-14 * float(np.max(np.abs(want[..., c - shift]))) if want.size else atol)
         np.testing.assert_allclose(got[..., c], want[..., c], rtol=POW_RTOL, atol=atol, err_msg="%s (state entry %d)" % (what, c))
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def env_var(name, value):
+    """Set (or with None: leave) an environment variable for the duration of a block."""
+    old = os.environ.get(name)
+    if value is not None:
+        os.environ[name] = value
+    try:
+        yield
+    finally:
+        if value is not None:
+            if old is None:
+                del os.environ[name]
+            else:
+                os.environ[name] = old

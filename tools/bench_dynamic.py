@@ -108,7 +108,7 @@ def main():
                    "env_steps_completed": env_steps,
                    "instances": [a.name for a in insts], "lp_threads": min(args.lp_threads or 16, os.cpu_count() or 1),
                    "lp_on_device": int(env.lp_on_device)},
-        "order_arrival_lps": lps, "lps_per_step": lps / args.steps, "lp_cache_hits_total": env.lp_cache_hits, "cpu_baseline": cpu}))
+        "order_arrival_lps": lps, "lps_per_step": lps / args.steps, "lp_cache_hits_total": env.lp_cache_hits, "lp_device_pivots_total": env.lp_device_pivots, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":
