@@ -885,12 +885,15 @@ GDEV bool rule_wants_gap_ave(uint32_t araw) {
 // EARLY: request the gap_ave rows together with the state (small batches: a wave is alone on its SIMD and nothing else hides
 // the memory round trip); otherwise they are fetched where they are used and the kernel keeps to 128 registers
 template <int V, int MPC, bool EARLY>
-__global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
+__global__ __launch_bounds__(EARLY ? 256 : 64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, const uint8_t *actions, const double *mo, int autoreset, double *state_out,
                                                    double *reward_out, uint8_t *done_out, int16_t *trace_km) {
     GE<V> e;
     GSTAMP_DECL;
     GSTAMP_BEGIN();
-    const int wave_id = (int)blockIdx.x;
+    // (small batches are launched four waves to a workgroup -- a quarter of the workgroups to dispatch; the waves never meet)
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_id = (int)blockIdx.x * (int)(blockDim.x >> 6) + wib;
+    unsigned char *const my_lds = g_lds + (size_t)wib * group_lds_bytes<MPC, EARLY>();
     // the action pair of the row's environment (2-byte aligned: checked by the host entry points)
     const int env_raw = wave_id * 4 + (int)(__lane_id() >> 4);
     const int env0 = min(env_raw, b.N - 1);
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, co
     }
     GCols<MPC> cr;
     bool gap_need = false;
-    g_open<V, EARLY>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), []() {});
+    g_open<V, EARLY>(e, b, wave_id, my_lds, group_rows<MPC, EARLY>(), []() {});
     gap_need = env_raw < b.N && rule_wants_gap_ave<V>(araw);
     const int a0 = (int)(araw & 0xFFu), a1 = (int)(araw >> 8);
     bool go = e.live;
@@ -933,13 +936,15 @@ __global__ __launch_bounds__(64, EARLY ? 1 : 4) void gstep_kernel(DevBatch b, co
 // T fused steps per launch with the actions given (rule sweeps): the environments live in registers for the whole
 // launch.  Same outputs as fjsp_kernels.hip rollout_kernel.
 template <int V, int MPC, bool EARLY>
-__global__ __launch_bounds__(64, EARLY ? 1 : 2) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
+__global__ __launch_bounds__(EARLY ? 256 : 64, EARLY ? 1 : 2) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
                                                       double *reward_out, double *state_last) {
     GE<V> e;
     GSTAMP_DECL;
     GSTAMP_BEGIN();
-    const int wave_id = (int)blockIdx.x;
-    g_open<V, EARLY>(e, b, wave_id, g_lds, group_rows<MPC, EARLY>(), []() {});
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_id = (int)blockIdx.x * (int)(blockDim.x >> 6) + wib;
+    unsigned char *const my_lds = g_lds + (size_t)wib * group_lds_bytes<MPC, EARLY>();
+    g_open<V, EARLY>(e, b, wave_id, my_lds, group_rows<MPC, EARLY>(), []() {});
     MoW mw = {0.0, 1.0, 0.0, 0.0};
     if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES && mo) {
         mw.w0 = mo[(size_t)e.env * 4]; mw.w1 = mo[(size_t)e.env * 4 + 1]; mw.cn = mo[(size_t)e.env * 4 + 2]; mw.tn = mo[(size_t)e.env * 4 + 3];
@@ -994,14 +999,25 @@ static size_t group_lds_pad() {
     static const size_t pad = [] { const char *v = getenv("FJSP_GROUP_LDS_PAD"); return v ? (size_t)atol(v) : (size_t)0; }();
     return pad;
 }
+template <typename K>
+static inline void group_allow_lds(K kernel, size_t lds) {          // (as allow_lds of fjsp_kernels.hip: on every launch, per device)
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+// small-batch kernels: waves per workgroup (FJSP_GROUP_WPB=1|2|4 for A/B runs)
+static unsigned group_waves_per_block() {
+    static const unsigned w = [] { const char *v = getenv("FJSP_GROUP_WPB"); const int x = v ? atoi(v) : 4; return (unsigned)(x == 1 || x == 2 ? x : 4); }();
+    return w;
+}
 template <int V>
 static int launch_step_group_v(const DevBatch &b, const uint8_t *actions, const double *mo, int autoreset, double *state, double *reward,
                                uint8_t *done, int16_t *trace_km, hipStream_t st) {
-    const dim3 grid((unsigned)((b.N + 3) / 4));
     const bool early = group_early(b);
-#define FJSP_GSTEP(MPC, E) hipLaunchKernelGGL((grp::gstep_kernel<V, MPC, E>), grid, dim3(64), (grp::group_lds_bytes<MPC, E>() + group_lds_pad()), st, b, actions, mo, autoreset, state, reward, done, trace_km)
-    if (b.MP <= 5) { if (early) FJSP_GSTEP(5, true); else FJSP_GSTEP(5, false); }
-    else { if (early) FJSP_GSTEP(8, true); else FJSP_GSTEP(8, false); }
+    const unsigned wpb = early ? group_waves_per_block() : 1u, waves = (unsigned)((b.N + 3) / 4);
+    const dim3 grid((waves + wpb - 1) / wpb);
+#define FJSP_GSTEP(MPC, E) group_allow_lds(&grp::gstep_kernel<V, MPC, E>, wpb * grp::group_lds_bytes<MPC, E>() + group_lds_pad()); hipLaunchKernelGGL((grp::gstep_kernel<V, MPC, E>), grid, dim3(64 * wpb), (wpb * grp::group_lds_bytes<MPC, E>() + group_lds_pad()), st, b, actions, mo, autoreset, state, reward, done, trace_km)
+    if (b.MP <= 5) { if (early) { FJSP_GSTEP(5, true); } else { FJSP_GSTEP(5, false); } }
+    else { if (early) { FJSP_GSTEP(8, true); } else { FJSP_GSTEP(8, false); } }
 #undef FJSP_GSTEP
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1017,11 +1033,12 @@ int launch_step_group(const DevBatch &b, const uint8_t *actions, const double *m
 template <int V>
 static int launch_rollout_group_v(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                                   double *state_last, hipStream_t st) {
-    const dim3 grid((unsigned)((b.N + 3) / 4));
     const bool early = group_early(b);
-#define FJSP_GROLL(MPC, E) hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64), (grp::group_lds_bytes<MPC, E>()), st, b, actions, mo, T, trace_km, reward, state_last)
-    if (b.MP <= 5) { if (early) FJSP_GROLL(5, true); else FJSP_GROLL(5, false); }
-    else { if (early) FJSP_GROLL(8, true); else FJSP_GROLL(8, false); }
+    const unsigned wpb = early ? group_waves_per_block() : 1u, waves = (unsigned)((b.N + 3) / 4);
+    const dim3 grid((waves + wpb - 1) / wpb);
+#define FJSP_GROLL(MPC, E) group_allow_lds(&grp::grollout_kernel<V, MPC, E>, wpb * grp::group_lds_bytes<MPC, E>()); hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64 * wpb), (wpb * grp::group_lds_bytes<MPC, E>()), st, b, actions, mo, T, trace_km, reward, state_last)
+    if (b.MP <= 5) { if (early) { FJSP_GROLL(5, true); } else { FJSP_GROLL(5, false); } }
+    else { if (early) { FJSP_GROLL(8, true); } else { FJSP_GROLL(8, false); } }
 #undef FJSP_GROLL
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--eager", action="store_true", help="launch every op of the rollout from Python instead of replaying the HIP graph")
     ap.add_argument("--per-step-rollout", action="store_true",
                     help="per-step rollout loop (policy, sampler, env kernel, buffer append per vector step) instead of the "
@@ -40,7 +40,9 @@ def main():
     torch.manual_seed(1234 + rank)
     agent = PPO(env, hidden_size=128, hidden_layer=2, seed=1, max_steps=56, use_graph=not args.eager, fused_sampling=not args.eager,
                 fused_rollout=not (args.eager or args.per_step_rollout))
-    agent.run_one_policy_network()          # warm-up round (allocations, kernel caches)
+    agent.run_one_policy_network()          # warm-up rounds: allocations and kernel caches, then the round in which the
+    agent.run_one_policy_network()          # learner captures its HIP graph (agents/MPPPO/MPPPO.py _learn_graphed); timed
+    agent.run_one_policy_network()          # rounds replay it
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps0 = agent.global_step_number
