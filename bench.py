@@ -268,17 +268,24 @@ def main():
         tpath = os.path.join(REPO, "profiles", "traffic_step_kernel.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("csrc_sha256") == csrc_hash() and N == tj.get("envs", 4096):
+            fresh = tj.get("csrc_sha256") == csrc_hash()
+            if fresh and N != tj.get("envs", 4096) and str(N) in tj.get("by_envs", {}):
+                traffic = tj["by_envs"][str(N)]["traffic_bytes_per_launch"]
+                traffic_note = tj["note"] + " (this batch size: %s)" % tj.get("by_envs_source", "tools/traffic_sizes.sh")
+            elif fresh and N == tj.get("envs", 4096):
                 traffic, traffic_note = tj["traffic_bytes_per_launch"], tj["note"]
-                if fused is not None and tj.get("fused_insts_per_wave_step"):
-                    ips = tj["fused_insts_per_wave_step"]
+                if fused is not None and tj.get("fused_insts_per_env_step"):
+                    ips = tj["fused_insts_per_env_step"]
                     peak = 1024 * 2.4e9 / ips                 # env-steps/s if every SIMD issued one instruction per cycle
-                    fused["issue_roofline"] = {"insts_per_wave_step": ips, "peak_env_steps_per_s": peak,
+                    fused["issue_roofline"] = {"insts_per_env_step": ips, "peak_env_steps_per_s": peak,
                                                "frac": fused["env_steps_per_s"] / peak,
-                                               "note": "1024 SIMDs x 2.4 GHz / instructions per wave-step (SQ_INSTS_VALU + SALU + LDS + "
-                                                       "SMEM + VMEM of rollout_kernel, PMC); f64 VALU instructions issue at 4 cycles, so "
-                                                       "the reachable fraction is below 1"}
+                                               "note": "1024 SIMDs x 2.4 GHz / wave instructions per env-step (SQ_INSTS_VALU + SALU + LDS + "
+                                                       "SMEM + VMEM of the fused kernel over the env-steps of its launch, PMC); a wave alone "
+                                                       "on its SIMD issues a dependent instruction every ~10 cycles, so the reachable "
+                                                       "fraction at 4096 environments is ~0.1"}
                     fused["bytes_per_env_episode"] = tj.get("fused_bytes_per_env_episode")
+            elif fresh:
+                traffic_note = "no PMC passes at this batch size are committed for this kernel source (tools/traffic_sizes.sh)"
             else:
                 traffic_note = "profiles/traffic_step_kernel.json was taken on another kernel source (%s): stale, not reported" \
                                % tj.get("commit", "?")

@@ -47,7 +47,24 @@ if rk and bench.get("fused"):
     insts = sum(rk.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD",
                                          "SQ_INSTS_VMEM_WR"))
     # (the profiled run alternates rollouts with and without a final state; the mean is over both)
-    out["fused_insts_per_wave_step"] = insts / rk["SQ_WAVES"] / steps_per_wave
+    # (instructions of all waves / env-steps of the launch: a wave of the row kernels steps four environments at once)
+    out["fused_insts_per_env_step"] = insts / rk["SQ_WAVES"] / steps_per_wave
     out["fused_bytes_per_env_episode"] = (rk["FETCH_SIZE"] * 1024 * 2.0 + rk["WRITE_SIZE"] * 1024) / rk["SQ_WAVES"]
+envs_per_wave = 4096.0 / sk["SQ_WAVES"]
+out["envs_per_wave"] = envs_per_wave
+out["insts_per_env_step"] = sum(out["insts_per_wave_step"].values()) / envs_per_wave
+# other batch sizes: a tools/traffic_sizes.sh summary (second argument), same corrections
+if len(sys.argv) > 2:
+    by = {}
+    for n, v in json.load(open(sys.argv[2])).items():
+        k = [k for k in v if "gstep_kernel" in k or "step_kernel<" in k]
+        if not k:
+            continue
+        c = v[k[0]]
+        by[n] = {"kernel": k[0], "traffic_bytes_per_launch": c["FETCH_SIZE"] * 1024 * 2.0 + c["WRITE_SIZE"] * 1024,
+                 "fetch_bytes_per_env_step": c["FETCH_SIZE"] * 1024 * 2.0 / int(n), "write_bytes_per_env_step": c["WRITE_SIZE"] * 1024 / int(n),
+                 "read_requests_128B_per_env_step": c.get("TCC_EA0_RDREQ_sum", 0.0) / int(n), "dispatches": c["dispatches"]}
+    out["by_envs"] = by
+    out["by_envs_source"] = os.path.relpath(sys.argv[2], REPO)
 json.dump(out, open(os.path.join(REPO, "profiles", "traffic_step_kernel.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
