@@ -200,7 +200,12 @@ int fjsp_env_step_traced(fjsp_env *e, const uint8_t *d_actions, const double *d_
  * one fjsp_env_step produces for the sequence of its APPLIED actions (parity is per env); only the interleaving across
  * envs differs.  fjsp_env_arrivals_flush waits for every parked env and finishes its step (rows + ready = 1);
  * it must run before fjsp_env_step / _reset / _rollout / destroy are used on the batch again (they return
- * FJSP_E_STATE while envs are parked).  fjsp_env_parked: parked envs as last seen by the host. */
+ * FJSP_E_STATE while envs are parked; so does fjsp_env_read).  fjsp_env_parked: parked envs as last seen by the host.
+ * DEVIATION from the reference's protocol (a single-threaded reset()/step() object): this service
+ * runs a dispatcher thread and a pool of LP worker threads inside the library for as long as the batch lives.  They touch
+ * only the batch's own staging buffers, never call back into the caller and are joined by fjsp_env_destroy; a caller that
+ * forks must do so before the first fjsp_env_step_async.  The blocking fjsp_env_step uses host threads only inside the
+ * call (and none at all when the LPs run on the device, fjsp_env_lp_on_device). */
 int fjsp_env_step_async(fjsp_env *e, const uint8_t *d_actions, const double *d_mo, int32_t autoreset, double *d_state,
                         double *d_reward, uint8_t *d_done, uint8_t *d_ready, void *stream);
 int fjsp_env_arrivals_flush(fjsp_env *e, const double *d_mo, double *d_state, double *d_reward, uint8_t *d_done,
