@@ -157,6 +157,8 @@ struct DevBatch {
     int32_t grp;             // 1 = the batch fits the group kernels (fjsp_group.hip): one job per kind, one order, <= 64 operation
                              // types, <= 8 machines, <= 15 jobs, SO_FJSSP or MO_FJSSP_discretes
     int32_t kmax;            // operation types of the largest instance
+    int kenv_first;          // large batches fetch kenv[env] before their operation words (1; FJSP_GROUP_KENV=0 for A/B runs: three
+                             // slots unconditionally, the fourth after K is known -- one dependent fetch less, 1-2 lines more: same speed)
     const uint8_t *kenv;     // row-kernel batches: operation types of the instance every environment plays, u8[N] (the large-batch
                              // kernels read it first and request no operation rows beyond it)
     uint32_t *pending_count; // [0] number of envs parked at an order arrival by the last launch, [1 + slot] their env ids

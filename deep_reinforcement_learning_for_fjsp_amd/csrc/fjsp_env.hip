@@ -620,6 +620,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         b.inst = reinterpret_cast<unsigned char *>(pi);
         b.envs = reinterpret_cast<unsigned char *>(pe);
         b.kenv = nullptr;
+        { const char *kv = getenv("FJSP_GROUP_KENV"); b.kenv_first = (kv && atoi(kv) == 0) ? 0 : 1; }
         if (b.grp) {       // operation types of every environment's instance (fjsp_group.hip: large-batch kernels)
             std::vector<uint8_t> kq(N);
             for (size_t q = 0; q < N; ++q) kq[q] = (uint8_t)s->v[(size_t)first + (NI == N ? q : q % NI)].K;

@@ -688,7 +688,8 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
     // ---- issue every load.  Operation rows: up to the batch's largest instance (small batches: one round trip), or up to
     // THIS environment's operation count, fetched first (large batches: a dependent fetch of one byte buys 2-4 lines of padding)
     int kq = b.kmax;
-    if (!EARLY) kq = (int)b.kenv[e.env];
+    if (!EARLY && !b.kenv_first) kq = min(b.kmax, 48);       // (the fourth slot, if this environment has one: below, once K is known)
+    if (!EARLY && b.kenv_first) kq = (int)b.kenv[e.env];         // (the count first, then only the words it has; A/B knob FJSP_GROUP_KENV=0)
     const unsigned char *op = ir + b.L.i_op;
     const uint32_t hw = reinterpret_cast<const uint32_t *>(op + 2048)[e.l];        // machine / job / instance words
     const int duej = reinterpret_cast<const int32_t *>(op + 2048 + 64)[e.l];
@@ -726,6 +727,10 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
         const int kw = max(max(k0, k1), max(k2, k3));
         e.nslots = (kw + 15) >> 4;
         e.n8w = max((kw + 7) & ~7, 8);
+    }
+    if (!EARLY && !b.kenv_first && b.kmax > 48 && e.nslots > 3) {
+        // more than 48 operation types in one of the wave's environments (rare at 10x5): one more round trip for the fourth slot
+        if (48 + e.l < e.K) A[3] = reinterpret_cast<const uint4 *>(op + 3 * 512)[e.l];
     }
 #pragma unroll
     for (int s = 0; s < GS; ++s) {
