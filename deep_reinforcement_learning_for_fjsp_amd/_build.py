@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("FJSP_AMD_LIB") or os.path.join(PKG_DIR, "libfjsp_amd.
 ORACLE_DIR = os.path.join(REPO_DIR, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libfjsp_oracle.so")
 
-HIP_SOURCES = ["fjsp_kernels.hip", "fjsp_group.hip", "fjsp_lp_device.hip", "fjsp_env.hip", "fjsp_rollout_buffer.hip", "fjsp_ppo.hip", "fjsp_mlp_train.hip"]
+HIP_SOURCES = ["fjsp_kernels.hip", "fjsp_group.hip", "fjsp_lp_device.hip", "fjsp_env.hip", "fjsp_rollout_buffer.hip", "fjsp_ppo.hip", "fjsp_mlp_train.hip", "fjsp_policy_mlp.hip"]
 CPP_SOURCES = ["fjsp_instance.cpp", "fjsp_lp.cpp"]
 
 

@@ -138,6 +138,8 @@ class SAC_Discrete(Base_Agent, Config):
         self.learn_sessions = 0
         self._last_losses = None
         self.use_graph = True            # replay the per-step device work and the update from captured HIP graphs (GPU only)
+        self.fused_policy = True         # draw the actions of the MLP policies in one launch per (task, machine) pair (GPU only)
+        self._sampler_seed = seed
         self._graphs, self._static, self._learn_graph = {}, None, None
 
     @property
@@ -155,9 +157,44 @@ class SAC_Discrete(Base_Agent, Config):
             self.policy_dict[policy] = {"task": task, "machine": machine}
 
     # -- acting ---------------------------------------------------------------------------------
+    # -- one-launch sampling (agents/fused_policy.py, csrc/fjsp_policy_mlp.hip): GPU batches, plain MLP stacks --------------
+    def _sampler(self, key):
+        """PolicyPairSampler of lower policy `key` (0|1|2) or of the controller's actor ("actor"); None when the fused
+        path is off or a network does not fit the kernel (the library path below is used then)."""
+        if not getattr(self, "fused_policy", True) or self.device.type != "cuda":
+            return None
+        cache = self.__dict__.setdefault("_samplers", {})
+        if key not in cache:
+            from .. import fused_policy
+            if key == "actor":
+                layers, layers_m = self.actor_local.layers, None
+            else:
+                nets = self.policy_dict[int(key)]
+                layers, layers_m = nets["task"].layers_1, nets["machine"].layers_2
+            ok = fused_policy.supported(layers, self.device) and (layers_m is None or fused_policy.supported(layers_m, self.device))
+            seed = int(getattr(self, "_sampler_seed", 0)) * 7919 + (97 if key == "actor" else 11 + int(key))
+            cache[key] = fused_policy.PolicyPairSampler(layers, layers_m, seed=seed) if ok else None
+        return cache[key]
+
     @torch.no_grad()
     def pick_lower_action(self, which, state):
         """:277-284 for a batch: env e follows lower policy which[e] (a scalar means everyone)."""
+        fused = state.is_cuda and state.dtype == torch.float64 and state.is_contiguous()
+        if fused and not torch.is_tensor(which):
+            sm = self._sampler(int(which))
+            if sm is not None:
+                a_t, a_m = sm.sample(state)
+                return torch.stack([a_t, a_m], 1).to(torch.uint8)
+        if fused and torch.is_tensor(which):
+            sms = {k: self._sampler(k) for k in self.policy_dict}
+            if all(v is not None for v in sms.values()):
+                a_t = torch.zeros(state.shape[0], dtype=torch.long, device=state.device)
+                a_m = torch.zeros_like(a_t)
+                for k, sm in sms.items():            # every lower policy proposes for every env, the controller's choice selects
+                    t, m = sm.sample(state)
+                    mine = which == k
+                    a_t, a_m = torch.where(mine, t, a_t), torch.where(mine, m, a_m)
+                return torch.stack([a_t, a_m], 1).to(torch.uint8)
         s = state.float()
         sample = lambda nets, x: Categorical(nets(x), validate_args=False).sample()
         if not torch.is_tensor(which):
@@ -181,6 +218,10 @@ class SAC_Discrete(Base_Agent, Config):
         """:248-254"""
         if self.global_step_number < self.hyper_parameters["min_steps_before_learning"]:
             return torch.randint(0, self.action_size, (state.shape[0],), device=self.device)
+        if state.is_cuda and state.dtype == torch.float64 and state.is_contiguous():
+            sm = self._sampler("actor")
+            if sm is not None:
+                return sm.sample(state)[0]
         action, _, _ = produce_action_and_action_info(self.actor_local, state.float())
         return action
 

@@ -1,0 +1,193 @@
+// Action sampling of the HMPSAC policies in ONE launch per (task, machine) pair
+// (agents/HMPSAC/SAC_Discrete.py:277-284 pick_lower_action, :248-254 pick_action; A3C_v5.1.py:35-75 the two policy networks).
+//
+// The reference evaluates, per environment step, TaskPolicyNet(state) -> Categorical sample a_t, then
+// MachinePolicyNet(cat(state, a_t)) -> Categorical sample a_m; batched over 4096 environments that is, through the library,
+// 4 GEMMs + bias / ReLU / softmax / multinomial kernels per network -- ~18 launches of ~4 us for 0.7 GFLOP, seven networks
+// per controller step.  Here a workgroup takes 8 environments through both networks: activations in LDS (two [8][256]
+// f32 buffers), thread j owns output neuron j of a layer for the 8 rows (8 accumulators; its weight row streamed from L2 as
+// float4, the inputs read from LDS as broadcast float4), then one lane per row does the softmax (expf(x - max) / sum, f32 as
+// torch) and draws the action by inverse CDF from a counter-based splitmix64 stream (seed, row, per-row draw counter kept in
+// device memory, so a launch replayed from a HIP graph keeps drawing fresh numbers).
+//
+// Supported shapes: Linear-ReLU-...-Linear with 1..6 linear layers, every width <= 256, <= 64 outputs.  Not a training path:
+// forward + sample only (the networks' updates stay where they were).
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/fjsp_amd.h"
+#include "fjsp_common.h"
+#include "fjsp_host.h"
+
+namespace {
+
+constexpr int kRows = 8;            // environments per workgroup
+constexpr int kWidth = 256;         // widest layer; threads per workgroup
+constexpr int kMaxLayers = 6;
+
+struct Mlp {
+    const float *W[kMaxLayers];     // [out][in] row-major (torch.nn.Linear.weight)
+    const float *B[kMaxLayers];
+    int dims[kMaxLayers + 1];       // dims[0] = inputs, dims[n] = outputs
+    int n;                          // linear layers (0 = network absent)
+};
+
+struct PairArgs {
+    Mlp task, machine;
+    const double *state;            // f64[rows][S]
+    int rows, S;
+    unsigned long long seed;
+    unsigned int *draws;            // u32[rows]: draws made so far by each row's stream
+    long long *a_task, *a_machine;  // i64[rows]
+    float *p_task, *p_machine;      // nullable: f32[rows][outputs], the probabilities the samples were drawn from
+};
+
+// One network over the workgroup's rows: in = act_a ([kRows][kWidth], first dims[0] columns valid), logits end up in the
+// buffer the function returns.
+__device__ float *mlp_forward(const Mlp &m, float *buf_a, float *buf_b, int tid) {
+    float *in = buf_a, *out = buf_b;
+    for (int l = 0; l < m.n; ++l) {
+        const int ni = m.dims[l], no = m.dims[l + 1];
+        if (tid < no) {
+            float acc[kRows];
+            const float bias = m.B[l][tid];
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) acc[r] = bias;
+            const float *w = m.W[l] + (size_t)tid * ni;
+            int i = 0;
+            if ((ni & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
+                for (; i + 4 <= ni; i += 4) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(w + i);
+#pragma unroll
+                    for (int r = 0; r < kRows; ++r) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(in + r * kWidth + i);
+                        acc[r] = fmaf(wv.x, xv.x, acc[r]); acc[r] = fmaf(wv.y, xv.y, acc[r]);
+                        acc[r] = fmaf(wv.z, xv.z, acc[r]); acc[r] = fmaf(wv.w, xv.w, acc[r]);
+                    }
+                }
+            }
+            for (; i < ni; ++i) {
+                const float wv = w[i];
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) acc[r] = fmaf(wv, in[r * kWidth + i], acc[r]);
+            }
+            const bool relu = l + 1 < m.n;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) out[r * kWidth + tid] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+        }
+        __syncthreads();
+        float *t = in; in = out; out = t;
+    }
+    return in;
+}
+
+// softmax of a row's logits (in place) and one draw from it; lane r of wave 0 handles row r
+__device__ int softmax_sample(float *logits, int no, unsigned long long seed, unsigned row, unsigned draw, float *probs_out) {
+    float mx = logits[0];
+    for (int a = 1; a < no; ++a) mx = fmaxf(mx, logits[a]);
+    float sum = 0.0f;
+    for (int a = 0; a < no; ++a) { const float e = expf(logits[a] - mx); logits[a] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    // u in [0, 1): 24 random bits, the stream of this row (fjsp_common.h splitmix64)
+    const unsigned long long h = fjsp::splitmix64(seed + (unsigned long long)row * 0x9E3779B97F4A7C15ull + (unsigned long long)draw * 1000003ull);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    int pick = no - 1;
+    float c = 0.0f;
+    bool found = false;
+    for (int a = 0; a < no; ++a) {
+        const float p = logits[a] * inv;
+        if (probs_out) probs_out[a] = p;
+        c += p;
+        if (!found && u < c) { pick = a; found = true; }
+    }
+    return pick;
+}
+
+__global__ __launch_bounds__(kWidth) void policy_pair_kernel(PairArgs a) {
+    __shared__ __attribute__((aligned(16))) float buf0[kRows * kWidth];
+    __shared__ __attribute__((aligned(16))) float buf1[kRows * kWidth];
+    __shared__ int s_task[kRows];
+    const int tid = (int)threadIdx.x;
+    const int row0 = (int)blockIdx.x * kRows;
+    // the rows' states as f32 (the reference's state.float())
+    for (int q = tid; q < kRows * a.S; q += kWidth) {
+        const int r = q / a.S, c = q - r * a.S;
+        const int row = min(row0 + r, a.rows - 1);
+        buf0[r * kWidth + c] = (float)a.state[(size_t)row * a.S + c];
+    }
+    __syncthreads();
+    float *logits = mlp_forward(a.task, buf0, buf1, tid);
+    const int no_t = a.task.dims[a.task.n];
+    if (tid < kRows) {
+        const int row = row0 + tid;
+        int pick = 0;
+        if (row < a.rows) {
+            const unsigned d = a.draws[row];
+            pick = softmax_sample(logits + tid * kWidth, no_t, a.seed, (unsigned)row, d, a.p_task ? a.p_task + (size_t)row * no_t : nullptr);
+            a.a_task[row] = pick;
+            a.draws[row] = d + (a.machine.n ? 2u : 1u);
+        }
+        s_task[tid] = pick;
+    }
+    __syncthreads();
+    if (!a.machine.n) return;
+    // machine network on cat(state, a_t)
+    for (int q = tid; q < kRows * (a.S + 1); q += kWidth) {
+        const int r = q / (a.S + 1), c = q - r * (a.S + 1);
+        const int row = min(row0 + r, a.rows - 1);
+        buf0[r * kWidth + c] = c < a.S ? (float)a.state[(size_t)row * a.S + c] : (float)s_task[r];
+    }
+    __syncthreads();
+    logits = mlp_forward(a.machine, buf0, buf1, tid);
+    const int no_m = a.machine.dims[a.machine.n];
+    if (tid < kRows) {
+        const int row = row0 + tid;
+        if (row < a.rows) {
+            const unsigned d = a.draws[row] - 1u;
+            a.a_machine[row] = softmax_sample(logits + tid * kWidth, no_m, a.seed, (unsigned)row, d, a.p_machine ? a.p_machine + (size_t)row * no_m : nullptr);
+        }
+    }
+}
+
+int fill(Mlp &m, int n_layers, const int32_t *dims, const float *const *weights, const float *const *biases, int want_in, const char *what) {
+    m.n = 0;
+    if (n_layers == 0) return FJSP_OK;
+    if (n_layers < 1 || n_layers > kMaxLayers || !dims || !weights || !biases) { fjsp::set_error(std::string("fjsp_policy_pair_sample: bad ") + what + " network description"); return FJSP_E_ARG; }
+    for (int l = 0; l <= n_layers; ++l)
+        if (dims[l] < 1 || dims[l] > kWidth) { fjsp::set_error(std::string("fjsp_policy_pair_sample: ") + what + " layer widths must be 1..256"); return FJSP_E_UNSUPPORTED; }
+    if (dims[n_layers] > 64) { fjsp::set_error(std::string("fjsp_policy_pair_sample: ") + what + " network has more than 64 outputs"); return FJSP_E_UNSUPPORTED; }
+    if (dims[0] != want_in) { fjsp::set_error(std::string("fjsp_policy_pair_sample: ") + what + " network's input width does not match the state"); return FJSP_E_ARG; }
+    for (int l = 0; l < n_layers; ++l) {
+        if (!weights[l] || !biases[l]) { fjsp::set_error("fjsp_policy_pair_sample: null parameter pointer"); return FJSP_E_ARG; }
+        m.W[l] = weights[l]; m.B[l] = biases[l];
+    }
+    for (int l = 0; l <= n_layers; ++l) m.dims[l] = dims[l];
+    m.n = n_layers;
+    return FJSP_OK;
+}
+
+}  // namespace
+
+extern "C" int fjsp_policy_pair_sample(int32_t task_layers, const int32_t *task_dims, const float *const *task_w, const float *const *task_b,
+                                       int32_t machine_layers, const int32_t *machine_dims, const float *const *machine_w,
+                                       const float *const *machine_b, const double *d_state, int32_t rows, int32_t state_size, uint64_t seed,
+                                       uint32_t *d_draws, int64_t *d_a_task, int64_t *d_a_machine, float *d_p_task, float *d_p_machine,
+                                       void *stream) {
+    if (!d_state || !d_draws || !d_a_task || rows <= 0 || state_size < 1 || state_size >= kWidth || (machine_layers && !d_a_machine)) {
+        fjsp::set_error("fjsp_policy_pair_sample: bad arguments"); return FJSP_E_ARG;
+    }
+    PairArgs a{};
+    int rc = fill(a.task, task_layers, task_dims, task_w, task_b, state_size, "task");
+    if (rc != FJSP_OK) return rc;
+    if (task_layers < 1) { fjsp::set_error("fjsp_policy_pair_sample: the task network is required"); return FJSP_E_ARG; }
+    rc = fill(a.machine, machine_layers, machine_dims, machine_w, machine_b, state_size + 1, "machine");
+    if (rc != FJSP_OK) return rc;
+    a.state = d_state; a.rows = rows; a.S = state_size; a.seed = seed; a.draws = d_draws;
+    a.a_task = reinterpret_cast<long long *>(d_a_task); a.a_machine = reinterpret_cast<long long *>(d_a_machine);
+    a.p_task = d_p_task; a.p_machine = d_p_machine;
+    hipLaunchKernelGGL(policy_pair_kernel, dim3((unsigned)((rows + kRows - 1) / kRows)), dim3(kWidth), 0, (hipStream_t)stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fjsp::set_error(std::string("fjsp_policy_pair_sample: ") + hipGetErrorString(e)); return FJSP_E_HIP; }
+    return FJSP_OK;
+}

@@ -381,6 +381,25 @@ int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, i
                         float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss,
                         void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * Action sampling of the HMPSAC policy networks in one launch
+ * (agents/HMPSAC/SAC_Discrete.py:277-284 pick_lower_action, :248-254 pick_action;
+ *  A3C_v5.1.py:35-75 TaskPolicyNet / MachinePolicyNet)
+ * ------------------------------------------------------------------------- */
+/* a_task ~ Categorical(softmax(task(state.float()))), then -- if machine_layers > 0 --
+ * a_machine ~ Categorical(softmax(machine(cat(state.float(), a_task)))) for `rows` states f64[rows][state_size].
+ * A network is Linear-ReLU-...-Linear: n linear layers (1..6), dims[n + 1] widths (each <= 256, outputs <= 64,
+ * dims[0] = state_size, resp. state_size + 1), weights[l] f32[dims[l+1]][dims[l]] row-major and biases[l] device
+ * pointers (torch.nn.Linear's own storage).  Randomness: a counter-based stream per row -- splitmix64(seed, row,
+ * d_draws[row]) -- whose draw counters u32[rows] live in device memory and advance with every call, so the launch can be
+ * replayed from a HIP graph.  d_p_task / d_p_machine (nullable): the f32 probabilities the actions were drawn from.
+ * Other shapes: FJSP_E_UNSUPPORTED (the caller keeps the library path). */
+int fjsp_policy_pair_sample(int32_t task_layers, const int32_t *task_dims, const float *const *task_w, const float *const *task_b,
+                            int32_t machine_layers, const int32_t *machine_dims, const float *const *machine_w,
+                            const float *const *machine_b, const double *d_state, int32_t rows, int32_t state_size, uint64_t seed,
+                            uint32_t *d_draws, int64_t *d_a_task, int64_t *d_a_machine, float *d_p_task, float *d_p_machine,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 csrc = os.path.join(REPO, "deep_reinforcement_learning_for_fjsp_amd", "csrc")
-srcs = [os.path.join(csrc, f) for f in ("fjsp_kernels.hip", "fjsp_env.hip", "fjsp_rollout_buffer.hip", "fjsp_ppo.hip", "fjsp_mlp_train.hip",
+srcs = [os.path.join(csrc, f) for f in ("fjsp_kernels.hip", "fjsp_env.hip", "fjsp_rollout_buffer.hip", "fjsp_ppo.hip", "fjsp_mlp_train.hip", "fjsp_policy_mlp.hip", "fjsp_group.hip", "fjsp_lp_device.hip",
                                          "fjsp_instance.cpp", "fjsp_lp.cpp")]
 BUILD_ONLY = "--build-only" in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
