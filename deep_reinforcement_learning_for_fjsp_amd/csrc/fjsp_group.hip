@@ -680,7 +680,11 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
     e.env = min(env_raw, b.N - 1);
     const int MP = b.MP, JP = b.JP;
     e.MP = MP;
-    const int inst = b.n_inst == b.N ? e.env : e.env % b.n_inst;
+    int inst = e.env;
+    if (b.n_inst != b.N) {                  // (a real branch: the ~25-instruction integer modulo stays off the usual path)
+        asm volatile("" ::: "memory");
+        inst = e.env % b.n_inst;
+    }
     const unsigned char *ir = b.inst + (size_t)inst * b.L.i_stride;
     unsigned char *er = b.envs + (size_t)e.env * FO::e_stride_plain((uint32_t)MP, (uint32_t)JP, 64u, true);
     e.ir = ir; e.er = er;
