@@ -997,12 +997,19 @@ extern "C" int fjsp_debug_read_gstamps(unsigned long long *out16, int reset) {
 #endif
 
 // ------------------------------------------------------------------ host launchers
-// Batches that leave the chip's SIMDs with at most two waves each (4 environments per wave, 1 024 SIMDs) run the variant that
-// requests Machine.gap_ave's rows ahead of time; larger ones the register-lean one.  FJSP_GROUP_EARLY=0/1 overrides (A/B runs).
-static bool group_early(const DevBatch &b) {
+// Which build of the step.  Per-step launches of batches that leave a SIMD a single wave (4 environments per wave, 1 024 SIMDs:
+// up to 4 096 environments, a little beyond) run the variant that requests everything at the top -- nothing else hides a
+// memory round trip there; larger batches the register-lean one (measured crossover between 4 096 and 6 144 environments:
+// 8.09 vs 8.43 us at 4 096, 9.29 vs 9.08 us at 6 144).  The fused kernel always runs the lean build: its environment stays
+// in registers and LDS across steps, the early build's requests are redundant there and its registers cost the second
+// wave (4 096 envs: 771 -> 905 M env-steps/s with states, 1.08 -> 1.40 G without; 8 192: 809 M -> 1.49 G).
+// FJSP_GROUP_EARLY=0/1 overrides both (A/B runs).
+static int group_early_forced() {
     static const int forced = [] { const char *v = getenv("FJSP_GROUP_EARLY"); return v ? atoi(v) : -1; }();
-    return forced >= 0 ? forced != 0 : b.N <= 8192;
+    return forced;
 }
+static bool group_early(const DevBatch &b) { return group_early_forced() >= 0 ? group_early_forced() != 0 : b.N <= 5120; }
+static bool group_early_rollout(const DevBatch &) { return group_early_forced() >= 0 ? group_early_forced() != 0 : false; }
 // DIAGNOSTIC knob (A/B runs of the occupancy a batch size needs): FJSP_GROUP_LDS_PAD=<bytes> of extra dynamic LDS per wave
 static size_t group_lds_pad() {
     static const size_t pad = [] { const char *v = getenv("FJSP_GROUP_LDS_PAD"); return v ? (size_t)atol(v) : (size_t)0; }();
@@ -1042,7 +1049,7 @@ int launch_step_group(const DevBatch &b, const uint8_t *actions, const double *m
 template <int V>
 static int launch_rollout_group_v(const DevBatch &b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km, double *reward,
                                   double *state_last, hipStream_t st) {
-    const bool early = group_early(b);
+    const bool early = group_early_rollout(b);
     const unsigned wpb = early ? group_waves_per_block() : 1u, waves = (unsigned)((b.N + 3) / 4);
     const dim3 grid((waves + wpb - 1) / wpb);
 #define FJSP_GROLL(MPC, E) group_allow_lds(&grp::grollout_kernel<V, MPC, E>, wpb * grp::group_lds_bytes<MPC, E>()); hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64 * wpb), (wpb * grp::group_lds_bytes<MPC, E>()), st, b, actions, mo, T, trace_km, reward, state_last)
