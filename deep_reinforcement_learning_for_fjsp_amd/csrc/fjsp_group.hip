@@ -147,6 +147,16 @@ __host__ __device__ constexpr int group_rows() { return EARLY ? MPC : 3; }
 template <int MPC, bool EARLY>
 __host__ __device__ constexpr size_t group_lds_bytes() { return (size_t)4 * group_rows<MPC, EARLY>() * KS * 8 + 256; }   // + the ring's read-ahead
 
+// Resident copy of an instance's static tables in LDS (fused kernel of batches that leave a CU at most four waves): the
+// fluid numbers of its operation types (B parts of the slots), the machine-major {arrival, rate} table and the processing
+// times.  A step of the lean build fetches these from memory three times in a row (current operations' fluid numbers ->
+// chosen operation's column -> the observation's fluid numbers); they never change during an episode.
+template <int MPC>
+__host__ __device__ constexpr uint32_t res_bytes() { return 2048u + (uint32_t)MPC * 1024u; }
+GDEV const double2 *res_B(uint32_t res) { return reinterpret_cast<const double2 *>(g_lds + res); }                   // [64] {rate sum, time sum}
+GDEV const uint16_t *res_P(uint32_t res) { return reinterpret_cast<const uint16_t *>(g_lds + res + 1024u); }         // [K][MP] as in memory (<= 1 KB)
+GDEV const double2 *res_C(uint32_t res) { return reinterpret_cast<const double2 *>(g_lds + res + 2048u); }           // [MP][64] {arrival, rate}
+
 // ------------------------------------------------------------------ row state
 struct MoW { double w0, w1, cn, tn; };      // MO_FJSSP_discretes.py:88 weight vector + normalisers (defaults: d_mo == NULL)
 
@@ -182,6 +192,9 @@ struct GE {
     long long tard_done, delay_sum;
     uint64_t env_seed;
     double *rows;              // this row's LDS rows
+    uint32_t res;              // fused kernel, small batches: byte offset (from g_lds) of this row's RESIDENT copy of the instance's
+                               // fluid numbers, {arrival, rate} table and processing times (g_make_resident)
+    int resident;              // wave-uniform (a kernel argument): the rows have resident copies; 0 = read from memory
 };
 
 // the (operation x machine) rows {arrival, rate} of a lane's slots, in flight while the step decides (g_cols_issue)
@@ -197,7 +210,9 @@ GDEV void g_gather_current(GE<V> &e, const DevBatch &b, bool want_rsum) {
         // large batches: the fluid numbers of the operation slots are not kept in registers between the start of a step and its
         // observation (resident waves hide the second fetch; the registers would cost a wave per SIMD): every job lane fetches
         // {fluid_rate_sum, fluid_time_sum} of its current operation type, the elig | fmask word comes out of the slots
-        const double2 rt = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + sl * 512 + 256)[src];
+        double2 rt;
+        if (e.resident) rt = res_B(e.res)[16 * sl + src];
+        else rt = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + sl * 512 + 256)[src];
         uint32_t a[GS];
 #pragma unroll
         for (int s = 0; s < GS; ++s) { a[s] = 0; if (SLOT_ON(e, s)) a[s] = greadu(e.em[s], src, e.gb); }
@@ -366,7 +381,9 @@ GDEV void g_gap_rows(const GE<V> &e, bool need, const GCols<MPC> &cr) {
 template <int V>
 GDEV double g_gap_ave_lean(const GE<V> &e, const DevBatch &b, bool need, uint32_t C) {
     const double dt = (double)e.t;
-    const double2 *colm = reinterpret_cast<const double2 *>(e.ir + b.L.i_colm);          // machine-major: [m][64]
+    const double2 *colm_g = reinterpret_cast<const double2 *>(e.ir + b.L.i_colm);        // machine-major: [m][64]
+    const double2 *colm_l = res_C(e.res);
+    auto colm_at = [&](int i) -> double2 { if (e.resident) return colm_l[i]; return colm_g[i]; };
     uint32_t rest = need ? C : 0u;
     double sum_m = 0.0;
     while (wave_any(rest != 0)) {
@@ -380,8 +397,8 @@ GDEV double g_gap_ave_lean(const GE<V> &e, const DevBatch &b, bool need, uint32_
                 const int k = 16 * s + e.l;
                 double *dst = e.rows + k;
                 // (entries of types that cannot run on the machine hold arrival = rate = 0: their gap is +0.0, see g_gap_rows)
-                const double2 a0 = colm[(m0 & 7) * 64 + k];
-                const double2 a1 = m1 < 8 ? colm[m1 * 64 + k] : make_double2(0.0, 0.0), a2 = m2 < 8 ? colm[m2 * 64 + k] : make_double2(0.0, 0.0);
+                const double2 a0 = colm_at((m0 & 7) * 64 + k);
+                const double2 a1 = m1 < 8 ? colm_at(m1 * 64 + k) : make_double2(0.0, 0.0), a2 = m2 < 8 ? colm_at(m2 * 64 + k) : make_double2(0.0, 0.0);
                 dst[0] = (asg == m0 ? a0.x - 1.0 : a0.x) - (a0.x - dt * a0.y);          // class_FJSSP.py:198, :304, :137-142
                 dst[KS] = (asg == m1 ? a1.x - 1.0 : a1.x) - (a1.x - dt * a1.y);
                 dst[2 * KS] = (asg == m2 ? a2.x - 1.0 : a2.x) - (a2.x - dt * a2.y);
@@ -431,8 +448,9 @@ GDEV int g_machine_select(GE<V> &e, const DevBatch &b, bool go, int a1, int k_se
         // contiguous entries per array.  k_sel has not been dispatched yet -- it is available -- so its unprocessed is
         // its arrival
         const int o = k_sel * e.MP + e.l;
-        pm = reinterpret_cast<const uint16_t *>(e.ir + b.L.i_p)[o];
-        const double2 ar = reinterpret_cast<const double2 *>(e.ir + b.L.i_col)[o];
+        double2 ar;
+        if (e.resident) { pm = res_P(e.res)[o]; ar = res_C(e.res)[e.l * 64 + k_sel]; }   // (the machine-major copy holds the same entries)
+        else { pm = reinterpret_cast<const uint16_t *>(e.ir + b.L.i_p)[o]; ar = reinterpret_cast<const double2 *>(e.ir + b.L.i_col)[o]; }
         g = ar.x - (ar.x - (double)e.t * ar.y);
     }
     const bool need3 = m_gave && gap_rows && (C & (C - 1)) != 0;     // (a list of one is returned without ranking it)
@@ -554,7 +572,10 @@ GDEV double g_observe(const GE<V> &e, const DevBatch &b, bool on, bool stats_onl
         rt[s] = make_double2(e.rsum[s], e.tsum[s]);
         if (!EARLY) {       // (large batches: the fluid numbers are fetched again, see g_gather_current)
             rt[s] = make_double2(0.0, 0.0);
-            if (SLOT_ON(e, s) && 16 * s + e.l < e.K) rt[s] = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + s * 512 + 256)[e.l];
+            if (SLOT_ON(e, s) && 16 * s + e.l < e.K) {
+                if (e.resident) rt[s] = res_B(e.res)[16 * s + e.l];
+                else rt[s] = reinterpret_cast<const double2 *>(e.ir + b.L.i_op + s * 512 + 256)[e.l];
+            }
         }
     }
 #pragma unroll
@@ -689,6 +710,7 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
     unsigned char *er = b.envs + (size_t)e.env * FO::e_stride_plain((uint32_t)MP, (uint32_t)JP, 64u, true);
     e.ir = ir; e.er = er;
     e.rows = reinterpret_cast<double *>(lds) + (size_t)(lane >> 4) * rows_per_env * KS;
+    e.res = 0u; e.resident = 0;
     // ---- issue every load.  Operation rows: up to the batch's largest instance (small batches: one round trip), or up to
     // THIS environment's operation count, fetched first (large batches: a dependent fetch of one byte buys 2-4 lines of padding)
     int kq = b.kmax;
@@ -889,6 +911,24 @@ GDEV bool rule_wants_gap_ave(uint32_t araw) {
     return (araw >> 8) == 3u;
 }
 
+// Copy the instance's static tables of this row's environment into its resident LDS block (once per fused launch)
+template <int V, int MPC>
+GDEV void g_make_resident(GE<V> &e, const DevBatch &b, uint32_t block_off) {
+    unsigned char *dst = g_lds + block_off;
+    double2 *B = reinterpret_cast<double2 *>(dst);
+    uint4 *P = reinterpret_cast<uint4 *>(dst + 1024u);
+    double2 *C = reinterpret_cast<double2 *>(dst + 2048u);
+    const unsigned char *op = e.ir + b.L.i_op;
+#pragma unroll
+    for (int s = 0; s < GS; ++s) B[16 * s + e.l] = reinterpret_cast<const double2 *>(op + s * 512 + 256)[e.l];
+    const uint4 *pg = reinterpret_cast<const uint4 *>(e.ir + b.L.i_p);                       // KP x MP u16, KP = 64: MP * 8 uint4
+    for (int q = e.l; q < e.MP * 8; q += 16) P[q] = pg[q];
+    const double2 *cg = reinterpret_cast<const double2 *>(e.ir + b.L.i_colm);
+    for (int q = e.l; q < e.MP * 64; q += 16) C[q] = cg[q];
+    lds_sync();
+    e.res = block_off; e.resident = 1;
+}
+
 // ------------------------------------------------------------------------ kernels
 // One step of every environment of a group batch (fjsp_kernels.hip step_kernel for the same batch gives the same results)
 // EARLY: request the gap_ave rows together with the state (small batches: a wave is alone on its SIMD and nothing else hides
@@ -946,7 +986,7 @@ __global__ __launch_bounds__(EARLY ? 256 : 64, EARLY ? 1 : 4) void gstep_kernel(
 // launch.  Same outputs as fjsp_kernels.hip rollout_kernel.
 template <int V, int MPC, bool EARLY>
 __global__ __launch_bounds__(EARLY ? 256 : 64, EARLY ? 1 : 2) void grollout_kernel(DevBatch b, const uint8_t *actions, const double *mo, int T, int16_t *trace_km,
-                                                      double *reward_out, double *state_last) {
+                                                      double *reward_out, double *state_last, int resident) {
     GE<V> e;
     GSTAMP_DECL;
     GSTAMP_BEGIN();
@@ -954,6 +994,8 @@ __global__ __launch_bounds__(EARLY ? 256 : 64, EARLY ? 1 : 2) void grollout_kern
     const int wave_id = (int)blockIdx.x * (int)(blockDim.x >> 6) + wib;
     unsigned char *const my_lds = g_lds + (size_t)wib * group_lds_bytes<MPC, EARLY>();
     g_open<V, EARLY>(e, b, wave_id, my_lds, group_rows<MPC, EARLY>(), []() {});
+    // (small batches, one wave to a workgroup: the static tables next to the rows, see res_bytes)
+    if (!EARLY && resident) g_make_resident<V, MPC>(e, b, (uint32_t)group_lds_bytes<MPC, EARLY>() + (uint32_t)(__lane_id() >> 4) * res_bytes<MPC>());
     MoW mw = {0.0, 1.0, 0.0, 0.0};
     if (V == FJSP_VARIANT_MO_FJSSP_DISCRETES && mo) {
         mw.w0 = mo[(size_t)e.env * 4]; mw.w1 = mo[(size_t)e.env * 4 + 1]; mw.cn = mo[(size_t)e.env * 4 + 2]; mw.tn = mo[(size_t)e.env * 4 + 3];
@@ -1052,7 +1094,14 @@ static int launch_rollout_group_v(const DevBatch &b, const uint8_t *actions, con
     const bool early = group_early_rollout(b);
     const unsigned wpb = early ? group_waves_per_block() : 1u, waves = (unsigned)((b.N + 3) / 4);
     const dim3 grid((waves + wpb - 1) / wpb);
-#define FJSP_GROLL(MPC, E) group_allow_lds(&grp::grollout_kernel<V, MPC, E>, wpb * grp::group_lds_bytes<MPC, E>()); hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64 * wpb), (wpb * grp::group_lds_bytes<MPC, E>()), st, b, actions, mo, T, trace_km, reward, state_last)
+    // resident static tables (lean build): when the waves a CU gets -- 256 CUs, one wave per workgroup -- fit its LDS with them
+    const unsigned waves_per_cu = (waves + 255u) / 256u;
+    const size_t res_lds = 4 * (size_t)(b.MP <= 5 ? grp::res_bytes<5>() : grp::res_bytes<8>());
+    const size_t lean_lds = b.MP <= 5 ? grp::group_lds_bytes<5, false>() : grp::group_lds_bytes<8, false>();
+    static const int res_forced = [] { const char *v = getenv("FJSP_GROUP_RESIDENT"); return v ? atoi(v) : -1; }();
+    const int resident = (!early && (res_forced >= 0 ? res_forced != 0 : waves_per_cu * (lean_lds + res_lds) <= (size_t)152 * 1024)) ? 1 : 0;
+    const size_t extra = resident ? res_lds : 0;
+#define FJSP_GROLL(MPC, E) group_allow_lds(&grp::grollout_kernel<V, MPC, E>, wpb * grp::group_lds_bytes<MPC, E>() + extra); hipLaunchKernelGGL((grp::grollout_kernel<V, MPC, E>), grid, dim3(64 * wpb), (wpb * grp::group_lds_bytes<MPC, E>() + extra), st, b, actions, mo, T, trace_km, reward, state_last, resident)
     if (b.MP <= 5) { if (early) { FJSP_GROLL(5, true); } else { FJSP_GROLL(5, false); } }
     else { if (early) { FJSP_GROLL(8, true); } else { FJSP_GROLL(8, false); } }
 #undef FJSP_GROLL
