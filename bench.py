@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the K timed launches from a captured HIP graph (auto: when K <= 256, where a region is launch-bound at its edges)")
     args = ap.parse_args()
 
     import numpy as np
@@ -116,12 +118,32 @@ def main():
     # launches lasts a fraction of a millisecond -- launch ramp-up and clock noise dominate it -- so the region is
     # repeated (at least 25 times and until 50 ms have been timed, at most 2 000 times) and the MEDIAN region is
     # reported; every region is the max over ranks.
+    # Short regions (the driver's --steps 20) are launch-bound at their edges: the K launches are captured once into a HIP
+    # graph and a region replays it -- the same K step launches on the same stream, one host call instead of K.
+    graph = None
+    if args.graph == "on" or (args.graph == "auto" and args.steps <= 256):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(3):
+                env.step(actions[i % Tbuf], autoreset=True)
+        torch.cuda.current_stream().wait_stream(side)
+        sync_all()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(args.steps):
+                env.step(actions[i % Tbuf], autoreset=True)
+        sync_all()
+
     def timed_region(k):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        for i in range(k):
-            env.step(actions[(step_ctr[0] + i) % Tbuf], autoreset=True)
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(k):
+                env.step(actions[(step_ctr[0] + i) % Tbuf], autoreset=True)
         ev1.record()
         sync_all()
         dt = time.perf_counter() - t0
@@ -249,9 +271,9 @@ def main():
         per_rank_value = [my_value]
 
     # the kernel that steps this batch: 16-lane-row family (csrc/fjsp_group.hip; its variant that requests gap_ave's rows ahead
-    # of time for batches of at most 8192 envs) or one wavefront per environment (csrc/fjsp_kernels.hip)
+    # of time for per-step launches of at most 5120 envs) or one wavefront per environment (csrc/fjsp_kernels.hip)
     if env.kernel_family == 1:
-        step_kernel_name = "grp::gstep_kernel<0, 5, %s>" % ("true" if N <= 8192 and os.environ.get("FJSP_GROUP_EARLY") != "0" else "false")
+        step_kernel_name = "grp::gstep_kernel<0, 5, %s>" % ("true" if (N <= 5120 and os.environ.get("FJSP_GROUP_EARLY") != "0") or os.environ.get("FJSP_GROUP_EARLY") == "1" else "false")
     else:
         step_kernel_name = "step_kernel<1, 0, true>"
     if rank == 0:
@@ -310,6 +332,8 @@ def main():
                                    "(seeds 1000+i), random policy, per-step HIP kernel (%s) with autoreset, "
                                    "one launch = one env step of every env" % (N, step_kernel_name),
                        "envs_per_gpu": N, "mean_ops_per_instance": float(K.mean()), "sharding": "env id range per rank, no collective",
+                       "launch": ("the K step launches of a timed region replayed from one captured HIP graph" if graph is not None
+                                  else "K step launches from the host per timed region"),
                        "host_prep_s": round(t_prep, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
