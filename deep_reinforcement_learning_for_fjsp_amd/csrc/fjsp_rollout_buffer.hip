@@ -104,6 +104,62 @@ __global__ void returns_normalise_kernel(int T, int N, float gamma, int normaliz
     }
 }
 
+// The same arithmetic, same order, for episodes of at most 64 steps (MPPPO's max_steps is 56): the episode's rewards and
+// validity flags are loaded once with all loads in flight, the four passes run in registers, one store per row.  The
+// kernel above walks memory four times with one thread per environment -- 0.12 ms of a 5.9 ms PPO round at 4096 envs.
+constexpr int kEpisodeRegs = 64;
+__global__ __launch_bounds__(64) void returns_normalise_regs_kernel(int T, int N, float gamma, int normalized, int standardized, const float *reward,
+                                                                   const float *valid, float *returns, float *out) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    float r[kEpisodeRegs], v[kEpisodeRegs];
+#pragma unroll
+    for (int t = 0; t < kEpisodeRegs; ++t) {
+        r[t] = 0.0f; v[t] = 0.0f;
+        if (t < T) { r[t] = reward[(size_t)t * N + env]; v[t] = valid[(size_t)t * N + env]; }
+    }
+    float g = 0.0f, gmin = 3.402823466e+38f, gmax = -3.402823466e+38f;
+    int cnt = 0;
+#pragma unroll
+    for (int t = kEpisodeRegs - 1; t >= 0; --t) {
+        if (t < T) {
+            if (v[t] != 0.0f) {
+                g = __fadd_rn(r[t], __fmul_rn(gamma, g));
+                r[t] = g;
+                gmin = fminf(gmin, g); gmax = fmaxf(gmax, g);
+                ++cnt;
+            } else {
+                r[t] = 0.0f;
+            }
+            returns[(size_t)t * N + env] = r[t];
+        }
+    }
+    const float span = __fadd_rn(__fsub_rn(gmax, gmin), 1e-8f);
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kEpisodeRegs; ++t) {
+        if (t < T && v[t] != 0.0f) {
+            if (normalized) r[t] = __fdiv_rn(__fsub_rn(r[t], gmin), span);
+            sum = __fadd_rn(sum, r[t]);
+        }
+    }
+    if (standardized) {
+        const float n = (float)(cnt > 1 ? cnt : 1), n1 = (float)(cnt - 1 > 1 ? cnt - 1 : 1);
+        const float mean = __fdiv_rn(sum, n);
+        float ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kEpisodeRegs; ++t)
+            if (t < T && v[t] != 0.0f) { const float d = __fsub_rn(r[t], mean); ss = __fadd_rn(ss, __fmul_rn(d, d)); }
+        const float denom = __fadd_rn(sqrtf(__fdiv_rn(ss, n1)), 1e-8f);
+#pragma unroll
+        for (int t = 0; t < kEpisodeRegs; ++t)
+            if (t < T && v[t] != 0.0f) r[t] = __fdiv_rn(__fsub_rn(r[t], mean), denom);
+    }
+#pragma unroll
+    for (int t = 0; t < kEpisodeRegs; ++t)
+        if (t < T) out[(size_t)t * N + env] = v[t] != 0.0f ? r[t] : 0.0f;
+}
+
 bool ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     fjsp::set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -206,8 +262,12 @@ int fjsp_rollout_returns_normalised(fjsp_rollout *b, double gamma, int32_t norma
     int prev = 0;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(b->device);
-    hipLaunchKernelGGL(returns_normalise_kernel, dim3((unsigned)((b->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->len, b->N, (float)gamma,
-                       (int)normalized, (int)standardized, b->rewards, b->valid, b->returns, d_out);
+    if (b->len <= kEpisodeRegs)
+        hipLaunchKernelGGL(returns_normalise_regs_kernel, dim3((unsigned)((b->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, b->len, b->N,
+                           (float)gamma, (int)normalized, (int)standardized, b->rewards, b->valid, b->returns, d_out);
+    else
+        hipLaunchKernelGGL(returns_normalise_kernel, dim3((unsigned)((b->N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->len, b->N, (float)gamma,
+                           (int)normalized, (int)standardized, b->rewards, b->valid, b->returns, d_out);
     const bool good = ok(hipGetLastError(), "returns_normalise_kernel");
     (void)hipSetDevice(prev);
     return good ? FJSP_OK : FJSP_E_HIP;

@@ -12,12 +12,13 @@ def torch_gpu(built):
     return torch
 
 
-def test_rollout_buffer_append_and_returns(torch_gpu):
+@pytest.mark.parametrize("T", [9, 58, 70])     # (episodes of <= 64 steps: the register-resident normalisation kernel; longer: the memory walk)
+def test_rollout_buffer_append_and_returns(torch_gpu, T):
     """fjsp_rollout_append == Buffer.py:41-45 `.float()` rows; fjsp_rollout_returns == MPPPO.py:301-312 scan."""
     torch = torch_gpu
     from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.Buffer import RolloutBuffer
     from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO.MPPPO import discounted_returns
-    T, N, S = 9, 37, 20
+    N, S = 37, 20
     buf = RolloutBuffer(T, N, S)
     g = torch.Generator(device="cuda").manual_seed(0)
     rows = []
@@ -28,7 +29,7 @@ def test_rollout_buffer_append_and_returns(torch_gpu):
         ac = torch.randint(0, 5, (N, 2), dtype=torch.uint8, device="cuda", generator=g)
         rw = -torch.randint(0, 300, (N,), device="cuda", generator=g).double()
         active = (done == 0).to(torch.uint8)
-        done = torch.maximum(done, (torch.rand(N, device="cuda", generator=g) < 0.2).to(torch.uint8))
+        done = torch.maximum(done, (torch.rand(N, device="cuda", generator=g) < (0.2 if T < 20 else 0.03)).to(torch.uint8))
         buf.add_experience(st, ac, rw, nx, done, active)
         rows.append((st, ac, rw, nx, done.clone(), active))
     n = len(buf)
