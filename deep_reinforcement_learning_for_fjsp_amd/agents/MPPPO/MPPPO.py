@@ -275,14 +275,24 @@ class PPOLearner(object):
             reduce = None
         actions_f = actions.to(torch.float32).contiguous()
         states, returns, old_log_prob = states.contiguous(), returns.contiguous(), old_log_prob.contiguous()
-        advantages = (returns - critic.forward(states).squeeze(1)).contiguous()                    # :263
         c_loss = a_loss = None
         one_launch = self.mfma_learn and actor.mfma_pass_supported() and critic.mfma_pass_supported()
-        for _ in range(hp["learning_iterations_per_round_critic"]):
+        # the advantages use the critic as it is BEFORE the round's updates (:263).  The first critic iteration's forward pass
+        # computes exactly those values: it hands them out and the separate forward pass (two library GEMMs) is not needed
+        values_from_first_pass = one_launch and reduce is None and self.train_critic
+        advantages = None
+        if not values_from_first_pass:
+            advantages = (returns - critic.forward(states).squeeze(1)).contiguous()                # :263
+        for it in range(hp["learning_iterations_per_round_critic"]):
             if one_launch and reduce is None:
                 # forward, loss, backward, clip + Adam of a network in three launches (single process: no all-reduce between)
                 if self.train_critic:
-                    c_loss = critic.train_step(1, states, returns, None, None, count)                       # F.mse_loss, :318
+                    if it == 0:
+                        values = torch.empty(states.shape[0], dtype=torch.float32, device=states.device)
+                        c_loss = critic.train_step(1, states, returns, None, None, count, values_out=values)   # F.mse_loss, :318
+                        advantages = returns - values                                                          # :263
+                    else:
+                        c_loss = critic.train_step(1, states, returns, None, None, count)
                 else:
                     c_loss = critic.train_pass(1, states, returns, None, None, count)
                 a_loss = actor.train_step(0, states, actions_f, old_log_prob, advantages, count, hp["clip_epsilon"])   # :325-352

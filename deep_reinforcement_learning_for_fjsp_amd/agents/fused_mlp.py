@@ -176,12 +176,21 @@ class FusedMLP(object):
         return b["loss"]
 
     @torch.no_grad()
-    def train_step(self, mode, x, aux0, aux1, aux2, count, clip_epsilon=0.0):
+    def train_step(self, mode, x, aux0, aux1, aux2, count, clip_epsilon=0.0, values_out=None):
         """train_pass() + step() of a single process in three launches (fjsp_mlp_train_step): the gradient finish also
-        produces the squared norm for the clip and advances the step count."""
+        produces the squared norm for the clip and advances the step count.  values_out (critic only): f32[n] that
+        receives V(x) as this pass's forward computed it, i.e. under the parameters before the update."""
         n = x.shape[0]
         self.train_pass_buffers(n)
         b = self._buf[("pass", n)]
+        if values_out is not None:
+            if int(mode) != 1 or values_out.dtype != torch.float32 or values_out.numel() != n or not values_out.is_contiguous() or values_out.device != x.device:
+                raise ValueError("train_step: values_out must be a contiguous f32[n] tensor on the samples' device (critic pass only)")
+            _capi.check(self._lib.fjsp_mlp_train_step_values(
+                1, _p(self.flat), _p(x), n, self.lin[0].in_features, self.H, self.out, _p(aux0), _p(aux1), _p(aux2), _p(count), float(clip_epsilon),
+                _p(b["partial"]), b["groups"], _p(b["loss_partial"]), _p(self.grad), _p(b["loss"]), _p(self.exp_avg), _p(self.exp_avg_sq),
+                self.max_norm, self.lr, self.betas[0], self.betas[1], self.eps, _p(self.step_count), _p(b["sumsq"]), _p(values_out), self._stream()))
+            return b["loss"]
         _capi.check(self._lib.fjsp_mlp_train_step(int(mode), _p(self.flat), _p(x), n, self.lin[0].in_features, self.H, self.out, _p(aux0),
                                                   _p(aux1), _p(aux2), _p(count), float(clip_epsilon), _p(b["partial"]), b["groups"],
                                                   _p(b["loss_partial"]), _p(self.grad), _p(b["loss"]), _p(self.exp_avg), _p(self.exp_avg_sq),

@@ -70,6 +70,7 @@ struct PassArgs {
     const float *count;       // [1] global sample count (the mean's denominator)
     float *partial;           // [gridDim.x][numel] gradient partials, parameter order
     float *loss_partial;      // [gridDim.x]
+    float *vout;              // critic, nullable: the value of every sample as this pass's forward computed it (before the update)
     int n, S, A, numel;
     float clip_eps;
 };
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(256) void mlp_train_pass_kernel(PassArgs p) {
             if (lg == 0) {
                 const float z = ((OUTp[ls * 32] + OUTp[TS * 32 + ls * 32]) + OUTp[2 * TS * 32 + ls * 32]) + OUTp[3 * TS * 32 + ls * 32];
                 float d = 0.0f;
+                if (valid && p.vout) p.vout[gs] = z;                                    // V(s) for the advantages (:263)
                 if (valid) {
                     const float dv = z - m0;                                            // F.mse_loss, :317-318
                     d = 2.0f * dv * inv_count;
@@ -580,7 +582,7 @@ namespace {
 int train_pass_launch(int32_t mode, const float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
                       const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon, float *d_partial,
                       int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_sumsq_partial, float *d_step, void *stream,
-                      int *numel_out) {
+                      int *numel_out, float *d_values_out = nullptr) {
     if (!d_params || !d_x || !d_aux0 || !d_count || !d_partial || !d_loss_partial || !d_grad || !d_loss || n <= 0 ||
         (mode != 0 && mode != 1) || (mode == 0 && (!d_aux1 || !d_aux2))) {
         fjsp::set_error("fjsp_mlp_train_pass: bad arguments"); return FJSP_E_ARG;
@@ -604,7 +606,7 @@ int train_pass_launch(int32_t mode, const float *d_params, const float *d_x, int
     }
     PassArgs a;
     a.params = d_params; a.x = d_x; a.aux0 = d_aux0; a.aux1 = d_aux1; a.aux2 = d_aux2; a.count = d_count;
-    a.partial = d_partial; a.loss_partial = d_loss_partial;
+    a.partial = d_partial; a.loss_partial = d_loss_partial; a.vout = mode == 1 ? d_values_out : nullptr;
     a.n = n; a.S = state_size; a.A = n_out; a.numel = H * state_size + H + H * H + H + n_out * H + n_out; a.clip_eps = clip_epsilon;
     if (mode == 0) hipLaunchKernelGGL(mlp_train_pass_kernel<0>, dim3(groups), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(mlp_train_pass_kernel<1>, dim3(groups), dim3(256), lds, (hipStream_t)stream, a);
@@ -628,15 +630,15 @@ int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, i
     return FJSP_OK;
 }
 
-int fjsp_mlp_train_step(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
-                        const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon,
-                        float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_exp_avg,
-                        float *d_exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, float *d_step,
-                        float *d_sumsq_partial, void *stream) {
+static int train_step_impl(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
+                           const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon,
+                           float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_exp_avg,
+                           float *d_exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, float *d_step,
+                           float *d_sumsq_partial, void *stream, float *d_values_out) {
     if (!d_exp_avg || !d_exp_avg_sq || !d_step || !d_sumsq_partial) { fjsp::set_error("fjsp_mlp_train_step: bad arguments"); return FJSP_E_ARG; }
     int numel = 0;
     const int rc = train_pass_launch(mode, d_params, d_x, n, state_size, hidden, n_out, d_aux0, d_aux1, d_aux2, d_count, clip_epsilon, d_partial,
-                                     n_groups, d_loss_partial, d_grad, d_loss, d_sumsq_partial, d_step, stream, &numel);
+                                     n_groups, d_loss_partial, d_grad, d_loss, d_sumsq_partial, d_step, stream, &numel, d_values_out);
     if (rc != FJSP_OK) return rc;
     const int blocks = std::min(256, (numel + 255) / 256);
     hipLaunchKernelGGL(adam_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_params, d_grad, d_exp_avg, d_exp_avg_sq, numel,
@@ -644,6 +646,27 @@ int fjsp_mlp_train_step(int32_t mode, float *d_params, const float *d_x, int32_t
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fjsp::set_error(std::string("fjsp_mlp_train_step: ") + hipGetErrorString(e)); return FJSP_E_HIP; }
     return FJSP_OK;
+}
+
+int fjsp_mlp_train_step(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
+                        const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon,
+                        float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_exp_avg,
+                        float *d_exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, float *d_step,
+                        float *d_sumsq_partial, void *stream) {
+    return train_step_impl(mode, d_params, d_x, n, state_size, hidden, n_out, d_aux0, d_aux1, d_aux2, d_count, clip_epsilon, d_partial, n_groups,
+                           d_loss_partial, d_grad, d_loss, d_exp_avg, d_exp_avg_sq, max_norm, lr, beta1, beta2, eps, d_step, d_sumsq_partial,
+                           stream, nullptr);
+}
+
+int fjsp_mlp_train_step_values(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden, int32_t n_out,
+                               const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count, float clip_epsilon,
+                               float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss, float *d_exp_avg,
+                               float *d_exp_avg_sq, float max_norm, float lr, float beta1, float beta2, float eps, float *d_step,
+                               float *d_sumsq_partial, float *d_values_out, void *stream) {
+    if (mode != 1 || !d_values_out) { fjsp::set_error("fjsp_mlp_train_step_values: the critic pass (mode 1) and an output buffer are required"); return FJSP_E_ARG; }
+    return train_step_impl(mode, d_params, d_x, n, state_size, hidden, n_out, d_aux0, d_aux1, d_aux2, d_count, clip_epsilon, d_partial, n_groups,
+                           d_loss_partial, d_grad, d_loss, d_exp_avg, d_exp_avg_sq, max_norm, lr, beta1, beta2, eps, d_step, d_sumsq_partial,
+                           stream, d_values_out);
 }
 
 }  // extern "C"

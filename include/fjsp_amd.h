@@ -381,6 +381,16 @@ int fjsp_mlp_train_pass(int32_t mode, const float *d_params, const float *d_x, i
                         float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad, float *d_loss,
                         void *stream);
 
+/* fjsp_mlp_train_step for the critic (mode 1) that also hands out what its forward computed: d_values_out f32[n] = V(s) of
+ * every sample under the parameters BEFORE this step's update -- the values the advantages of the round are built from
+ * (MPPPO.py:263 returns - critic(states)), so the first critic iteration of a learning round replaces the separate
+ * forward pass. */
+int fjsp_mlp_train_step_values(int32_t mode, float *d_params, const float *d_x, int32_t n, int32_t state_size, int32_t hidden,
+                               int32_t n_out, const float *d_aux0, const float *d_aux1, const float *d_aux2, const float *d_count,
+                               float clip_epsilon, float *d_partial, int32_t n_groups, float *d_loss_partial, float *d_grad,
+                               float *d_loss, float *d_exp_avg, float *d_exp_avg_sq, float max_norm, float lr, float beta1,
+                               float beta2, float eps, float *d_step, float *d_sumsq_partial, float *d_values_out, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Action sampling of the HMPSAC policy networks in one launch
  * (agents/HMPSAC/SAC_Discrete.py:277-284 pick_lower_action, :248-254 pick_action;

@@ -634,3 +634,35 @@ def test_one_launch_policy_pair_sampling(torch_gpu, rows, hidden, layers):
     assert not fused_policy.supported(wide.layers_1)
     with pytest.raises(ValueError):
         fused_policy.PolicyPairSampler(wide.layers_1)
+
+
+@pytest.mark.gpu
+def test_critic_step_hands_out_the_values_of_its_forward_pass(torch_gpu):
+    """fjsp_mlp_train_step_values: the critic's training step also returns V(s) under the parameters BEFORE the update
+    (what MPPPO.py:263 builds the advantages from): equal to the network's own forward pass (f32 reassociation), and the
+    step itself is the one fjsp_mlp_train_step takes."""
+    import copy
+    torch = torch_gpu
+    from deep_reinforcement_learning_for_fjsp_amd.agents.MPPPO import MPPPO as M
+    from deep_reinforcement_learning_for_fjsp_amd.agents import fused_mlp
+    dev = torch.device("cuda", 0)
+    n, S = 70001, 20
+    g = torch.Generator(device="cuda").manual_seed(3)
+    torch.manual_seed(9)
+    net_a = M.CriticNet(S, 128, 2, 1).to(dev)
+    net_b = copy.deepcopy(net_a)
+    x = torch.randn(n, S, device=dev, generator=g)
+    returns = torch.randn(n, device=dev, generator=g)
+    count = torch.full((1,), float(n), device=dev)
+    with torch.no_grad():
+        want = net_a(x).squeeze(1).clone()
+    ta, tb = fused_mlp.FusedMLP(net_a.layers, lr=1e-3, max_norm=1.0), fused_mlp.FusedMLP(net_b.layers, lr=1e-3, max_norm=1.0)
+    values = torch.full((n,), float("nan"), device=dev)
+    la = ta.train_step(1, x, returns, None, None, count, values_out=values).clone()
+    lb = tb.train_step(1, x, returns, None, None, count).clone()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(values.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert float(la) == float(lb)
+    assert torch.equal(ta.flat, tb.flat)
+    with pytest.raises(ValueError):
+        ta.train_step(0, x, returns, returns, returns, count, values_out=values)
