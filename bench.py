@@ -40,12 +40,13 @@ REFERENCE_PYTHON_STEPS_PER_S = 1700.0
 
 def csrc_hash():
     """sha256 over the sources the environment kernels are compiled from: ties a committed PMC figure to the code it
-    was measured on (the agents' kernels -- fjsp_ppo.hip, fjsp_mlp_train.hip, fjsp_policy_mlp.hip -- are not part of the measured launch)."""
+    was measured on (the agents' kernels -- fjsp_ppo.hip, fjsp_mlp_train.hip, fjsp_policy_mlp.hip, fjsp_rollout_buffer.hip -- are not part of the measured
+    launch)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(REPO, "deep_reinforcement_learning_for_fjsp_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h", ".cpp")) and f not in ("fjsp_ppo.hip", "fjsp_mlp_train.hip", "fjsp_policy_mlp.hip"):
+        if f.endswith((".hip", ".h", ".cpp")) and f not in ("fjsp_ppo.hip", "fjsp_mlp_train.hip", "fjsp_policy_mlp.hip", "fjsp_rollout_buffer.hip"):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
