@@ -283,6 +283,29 @@ class PPOLearner(object):
         advantages = None
         if not values_from_first_pass:
             advantages = (returns - critic.forward(states).squeeze(1)).contiguous()                # :263
+        if values_from_first_pass and getattr(self, "two_chains", True):
+            # The critic's iterations and the actor's are two independent chains once the advantages exist (the actor never
+            # reads the critic's new parameters inside a round, :314-323): they are issued on two streams, so the small
+            # launches of one chain (gradient finish, clip + Adam: 0.28 ms of a round in sequence) run under the other's pass.
+            n_it = hp["learning_iterations_per_round_critic"]
+            main = torch.cuda.current_stream(states.device)
+            side = self.__dict__.get("_actor_stream")
+            if side is None:
+                side = self._actor_stream = torch.cuda.Stream(device=states.device)
+            values = torch.empty(states.shape[0], dtype=torch.float32, device=states.device)
+            c_loss = critic.train_step(1, states, returns, None, None, count, values_out=values)           # F.mse_loss, :318
+            advantages = returns - values                                                                  # :263
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(n_it):
+                    a_loss = actor.train_step(0, states, actions_f, old_log_prob, advantages, count, hp["clip_epsilon"])   # :325-352
+            for _ in range(n_it - 1):
+                c_loss = critic.train_step(1, states, returns, None, None, count)
+            main.wait_stream(side)
+            for t in (advantages, actions_f, states, old_log_prob, count):
+                t.record_stream(side)
+            self.equalise_policies()
+            return c_loss[0].clone(), a_loss[0].clone()
         for it in range(hp["learning_iterations_per_round_critic"]):
             if one_launch and reduce is None:
                 # forward, loss, backward, clip + Adam of a network in three launches (single process: no all-reduce between)
