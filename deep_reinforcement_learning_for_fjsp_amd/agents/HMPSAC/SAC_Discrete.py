@@ -173,7 +173,9 @@ class SAC_Discrete(Base_Agent, Config):
                 layers, layers_m = nets["task"].layers_1, nets["machine"].layers_2
             ok = fused_policy.supported(layers, self.device) and (layers_m is None or fused_policy.supported(layers_m, self.device))
             seed = int(getattr(self, "_sampler_seed", 0)) * 7919 + (97 if key == "actor" else 11 + int(key))
-            cache[key] = fused_policy.PolicyPairSampler(layers, layers_m, seed=seed) if ok else None
+            # (the lower policies are frozen inside the controller's training: their transposed weights are taken once;
+            # the actor's at every call)
+            cache[key] = fused_policy.PolicyPairSampler(layers, layers_m, seed=seed, static_weights=key != "actor") if ok else None
         return cache[key]
 
     @torch.no_grad()

@@ -6,8 +6,8 @@ actor, SAC_Discrete.py:85-103):  sample(state) -> (a_task, a_machine) int64 tens
 softmax(task(state.float())) and softmax(machine(cat(state.float(), a_task))) exactly as
 SAC_Discrete.py:277-284 does with two Categorical objects -- same distributions, but the random numbers come from a
 counter-based splitmix64 stream per row (seed, row, draws made so far) instead of torch's generator, like the
-environment kernels' own streams.  The parameter pointers are read at every call (the storage of torch.nn.Linear
-parameters is stable under in-place optimiser steps), so a call captured into a HIP graph follows later updates.
+environment kernels' own streams.  The kernel reads transposed copies of the weights, refreshed at every call unless the
+sampler was built with static_weights=True (frozen networks), so a call captured into a HIP graph follows later updates.
 
 GPU only; `supported()` says whether a stack fits the kernel (<= 6 linear layers, widths <= 256, <= 64 outputs, f32).
 """
@@ -49,26 +49,39 @@ def supported(layers, device=None):
 
 
 class _Net:
-    def __init__(self, layers):
+    """Parameter pointers of one stack as the kernel wants them: the weights TRANSPOSED ([in][out]: the threads of a wave
+    then read consecutive words), kept in buffers of this object.  static_weights=True: the transposes are taken once
+    (networks nobody updates any more); False: at every refresh(), i.e. at every sampling call -- one small copy kernel
+    per layer, also when the call is captured into a HIP graph, so replays follow in-place optimiser steps."""
+
+    def __init__(self, layers, static_weights):
         self.lin = _linears(layers)
         self.n = len(self.lin)
         self.dims = np.array([self.lin[0].in_features] + [m.out_features for m in self.lin], dtype=np.int32)
+        self.static = bool(static_weights)
+        self.wt = [torch.empty(m.in_features, m.out_features, dtype=torch.float32, device=m.weight.device) for m in self.lin]
         self.w = (C.c_void_p * self.n)()
         self.b = (C.c_void_p * self.n)()
+        self._filled = False
 
+    @torch.no_grad()
     def refresh(self):
+        if not (self.static and self._filled):
+            for t, m in zip(self.wt, self.lin):
+                t.copy_(m.weight.t())
+            self._filled = True
         for i, m in enumerate(self.lin):
-            self.w[i] = m.weight.data_ptr()
+            self.w[i] = self.wt[i].data_ptr()
             self.b[i] = m.bias.data_ptr()
 
 
 class PolicyPairSampler:
-    def __init__(self, task_layers, machine_layers=None, seed=0):
+    def __init__(self, task_layers, machine_layers=None, seed=0, static_weights=False):
         if not supported(task_layers) or (machine_layers is not None and not supported(machine_layers)):
             raise ValueError("PolicyPairSampler: unsupported network (Linear-ReLU-...-Linear, f32 on a GPU, widths <= 256, outputs <= 64)")
         self._lib = _capi.lib()
-        self.task = _Net(task_layers)
-        self.machine = _Net(machine_layers) if machine_layers is not None else None
+        self.task = _Net(task_layers, static_weights)
+        self.machine = _Net(machine_layers, static_weights) if machine_layers is not None else None
         self.device = self.task.lin[0].weight.device
         self.S = int(self.task.dims[0])
         if self.machine is not None and int(self.machine.dims[0]) != self.S + 1:

@@ -4,11 +4,13 @@
 // The reference evaluates, per environment step, TaskPolicyNet(state) -> Categorical sample a_t, then
 // MachinePolicyNet(cat(state, a_t)) -> Categorical sample a_m; batched over 4096 environments that is, through the library,
 // 4 GEMMs + bias / ReLU / softmax / multinomial kernels per network -- ~18 launches of ~4 us for 0.7 GFLOP, seven networks
-// per controller step.  Here a workgroup takes 8 environments through both networks: activations in LDS (two [8][256]
-// f32 buffers), thread j owns output neuron j of a layer for the 8 rows (8 accumulators; its weight row streamed from L2 as
-// float4, the inputs read from LDS as broadcast float4), then one lane per row does the softmax (expf(x - max) / sum, f32 as
-// torch) and draws the action by inverse CDF from a counter-based splitmix64 stream (seed, row, per-row draw counter kept in
-// device memory, so a launch replayed from a HIP graph keeps drawing fresh numbers).
+// per controller step.  Here a workgroup takes 16 environments through both networks: activations in LDS (two [256][16]
+// f32 buffers, the 16 rows of a feature contiguous), thread j owns output neuron j of a layer for the 16 rows (16
+// accumulators; per input one weight load -- the weights are passed TRANSPOSED, [in][out], so the threads of a wave read
+// consecutive words: with torch's [out][in] every lane streams its own row, a wave touches 64 cache lines per load and the
+// launch moves 8x the weights through L2 -- and four broadcast float4 reads of the inputs), then one lane per row does the
+// softmax (expf(x - max) / sum, f32 as torch) and draws the action by inverse CDF from a counter-based splitmix64 stream
+// (seed, row, per-row draw counter kept in device memory, so a launch replayed from a HIP graph keeps drawing fresh numbers).
 //
 // Supported shapes: Linear-ReLU-...-Linear with 1..6 linear layers, every width <= 256, <= 64 outputs.  Not a training path:
 // forward + sample only (the networks' updates stay where they were).
@@ -22,12 +24,14 @@
 
 namespace {
 
-constexpr int kRows = 8;            // environments per workgroup
+constexpr int kRows = 16;           // environments per workgroup
 constexpr int kWidth = 256;         // widest layer; threads per workgroup
 constexpr int kMaxLayers = 6;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Mlp {
-    const float *W[kMaxLayers];     // [out][in] row-major (torch.nn.Linear.weight)
+    const float *W[kMaxLayers];     // [in][out] row-major: the TRANSPOSE of torch.nn.Linear.weight
     const float *B[kMaxLayers];
     int dims[kMaxLayers + 1];       // dims[0] = inputs, dims[n] = outputs
     int n;                          // linear layers (0 = network absent)
@@ -43,38 +47,48 @@ struct PairArgs {
     float *p_task, *p_machine;      // nullable: f32[rows][outputs], the probabilities the samples were drawn from
 };
 
-// One network over the workgroup's rows: in = act_a ([kRows][kWidth], first dims[0] columns valid), logits end up in the
-// buffer the function returns.
+// One network over the workgroup's rows: activations as [feature][kRows]; in = buf_a (first dims[0] features valid), the
+// logits end up in the buffer the function returns.
 __device__ float *mlp_forward(const Mlp &m, float *buf_a, float *buf_b, int tid) {
     float *in = buf_a, *out = buf_b;
     for (int l = 0; l < m.n; ++l) {
         const int ni = m.dims[l], no = m.dims[l + 1];
         if (tid < no) {
-            float acc[kRows];
+            // 16 accumulators as 8 pairs: v_pk_fma_f32 does two f32 FMAs per lane and instruction (the rate the chip's f32
+            // vector peak is quoted at); one weight (broadcast to both halves) times two rows' inputs.  (Tried: every wave
+            // taking four rows through all neurons, four neurons per lane -- a quarter of the LDS reads, but every wave then
+            // streams all the weights: 178 us against 71.)
+            v2f acc[kRows / 2];
             const float bias = m.B[l][tid];
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) acc[r] = bias;
-            const float *w = m.W[l] + (size_t)tid * ni;
+            for (int r = 0; r < kRows / 2; ++r) acc[r] = v2f{bias, bias};
+            const float *w = m.W[l] + tid;                       // column tid of the transposed weights: stride no
             int i = 0;
-            if ((ni & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
-                for (; i + 4 <= ni; i += 4) {
-                    const float4 wv = *reinterpret_cast<const float4 *>(w + i);
+            for (; i + 4 <= ni; i += 4) {                        // (four weight loads in flight)
+                const float w0 = w[(size_t)i * no], w1 = w[(size_t)(i + 1) * no], w2 = w[(size_t)(i + 2) * no], w3 = w[(size_t)(i + 3) * no];
+                const v2f W0 = {w0, w0}, W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3};
 #pragma unroll
-                    for (int r = 0; r < kRows; ++r) {
-                        const float4 xv = *reinterpret_cast<const float4 *>(in + r * kWidth + i);
-                        acc[r] = fmaf(wv.x, xv.x, acc[r]); acc[r] = fmaf(wv.y, xv.y, acc[r]);
-                        acc[r] = fmaf(wv.z, xv.z, acc[r]); acc[r] = fmaf(wv.w, xv.w, acc[r]);
-                    }
+                for (int q = 0; q < kRows / 4; ++q) {
+                    const v4f x0 = *reinterpret_cast<const v4f *>(in + (i + 0) * kRows + 4 * q), x1 = *reinterpret_cast<const v4f *>(in + (i + 1) * kRows + 4 * q);
+                    const v4f x2 = *reinterpret_cast<const v4f *>(in + (i + 2) * kRows + 4 * q), x3 = *reinterpret_cast<const v4f *>(in + (i + 3) * kRows + 4 * q);
+                    acc[2 * q] = __builtin_elementwise_fma(W0, x0.xy, acc[2 * q]); acc[2 * q + 1] = __builtin_elementwise_fma(W0, x0.zw, acc[2 * q + 1]);
+                    acc[2 * q] = __builtin_elementwise_fma(W1, x1.xy, acc[2 * q]); acc[2 * q + 1] = __builtin_elementwise_fma(W1, x1.zw, acc[2 * q + 1]);
+                    acc[2 * q] = __builtin_elementwise_fma(W2, x2.xy, acc[2 * q]); acc[2 * q + 1] = __builtin_elementwise_fma(W2, x2.zw, acc[2 * q + 1]);
+                    acc[2 * q] = __builtin_elementwise_fma(W3, x3.xy, acc[2 * q]); acc[2 * q + 1] = __builtin_elementwise_fma(W3, x3.zw, acc[2 * q + 1]);
                 }
             }
             for (; i < ni; ++i) {
-                const float wv = w[i];
+                const float wv = w[(size_t)i * no];
+                const v2f Wv = {wv, wv};
 #pragma unroll
-                for (int r = 0; r < kRows; ++r) acc[r] = fmaf(wv, in[r * kWidth + i], acc[r]);
+                for (int r = 0; r < kRows / 2; ++r) acc[r] = __builtin_elementwise_fma(Wv, *reinterpret_cast<const v2f *>(in + i * kRows + 2 * r), acc[r]);
             }
             const bool relu = l + 1 < m.n;
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) out[r * kWidth + tid] = relu ? fmaxf(acc[r], 0.0f) : acc[r];
+            for (int r = 0; r < kRows / 2; ++r) {
+                out[tid * kRows + 2 * r] = relu ? fmaxf(acc[r].x, 0.0f) : acc[r].x;
+                out[tid * kRows + 2 * r + 1] = relu ? fmaxf(acc[r].y, 0.0f) : acc[r].y;
+            }
         }
         __syncthreads();
         float *t = in; in = out; out = t;
@@ -84,10 +98,11 @@ __device__ float *mlp_forward(const Mlp &m, float *buf_a, float *buf_b, int tid)
 
 // softmax of a row's logits (in place) and one draw from it; lane r of wave 0 handles row r
 __device__ int softmax_sample(float *logits, int no, unsigned long long seed, unsigned row, unsigned draw, float *probs_out) {
+    // (logits of this row: element a at logits[a * kRows])
     float mx = logits[0];
-    for (int a = 1; a < no; ++a) mx = fmaxf(mx, logits[a]);
+    for (int a = 1; a < no; ++a) mx = fmaxf(mx, logits[a * kRows]);
     float sum = 0.0f;
-    for (int a = 0; a < no; ++a) { const float e = expf(logits[a] - mx); logits[a] = e; sum += e; }
+    for (int a = 0; a < no; ++a) { const float e = expf(logits[a * kRows] - mx); logits[a * kRows] = e; sum += e; }
     const float inv = 1.0f / sum;
     // u in [0, 1): 24 random bits, the stream of this row (fjsp_common.h splitmix64)
     const unsigned long long h = fjsp::splitmix64(seed + (unsigned long long)row * 0x9E3779B97F4A7C15ull + (unsigned long long)draw * 1000003ull);
@@ -96,7 +111,7 @@ __device__ int softmax_sample(float *logits, int no, unsigned long long seed, un
     float c = 0.0f;
     bool found = false;
     for (int a = 0; a < no; ++a) {
-        const float p = logits[a] * inv;
+        const float p = logits[a * kRows] * inv;
         if (probs_out) probs_out[a] = p;
         c += p;
         if (!found && u < c) { pick = a; found = true; }
@@ -114,7 +129,7 @@ __global__ __launch_bounds__(kWidth) void policy_pair_kernel(PairArgs a) {
     for (int q = tid; q < kRows * a.S; q += kWidth) {
         const int r = q / a.S, c = q - r * a.S;
         const int row = min(row0 + r, a.rows - 1);
-        buf0[r * kWidth + c] = (float)a.state[(size_t)row * a.S + c];
+        buf0[c * kRows + r] = (float)a.state[(size_t)row * a.S + c];
     }
     __syncthreads();
     float *logits = mlp_forward(a.task, buf0, buf1, tid);
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(kWidth) void policy_pair_kernel(PairArgs a) {
         int pick = 0;
         if (row < a.rows) {
             const unsigned d = a.draws[row];
-            pick = softmax_sample(logits + tid * kWidth, no_t, a.seed, (unsigned)row, d, a.p_task ? a.p_task + (size_t)row * no_t : nullptr);
+            pick = softmax_sample(logits + tid, no_t, a.seed, (unsigned)row, d, a.p_task ? a.p_task + (size_t)row * no_t : nullptr);
             a.a_task[row] = pick;
             a.draws[row] = d + (a.machine.n ? 2u : 1u);
         }
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(kWidth) void policy_pair_kernel(PairArgs a) {
     for (int q = tid; q < kRows * (a.S + 1); q += kWidth) {
         const int r = q / (a.S + 1), c = q - r * (a.S + 1);
         const int row = min(row0 + r, a.rows - 1);
-        buf0[r * kWidth + c] = c < a.S ? (float)a.state[(size_t)row * a.S + c] : (float)s_task[r];
+        buf0[c * kRows + r] = c < a.S ? (float)a.state[(size_t)row * a.S + c] : (float)s_task[r];
     }
     __syncthreads();
     logits = mlp_forward(a.machine, buf0, buf1, tid);
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(kWidth) void policy_pair_kernel(PairArgs a) {
         const int row = row0 + tid;
         if (row < a.rows) {
             const unsigned d = a.draws[row] - 1u;
-            a.a_machine[row] = softmax_sample(logits + tid * kWidth, no_m, a.seed, (unsigned)row, d, a.p_machine ? a.p_machine + (size_t)row * no_m : nullptr);
+            a.a_machine[row] = softmax_sample(logits + tid, no_m, a.seed, (unsigned)row, d, a.p_machine ? a.p_machine + (size_t)row * no_m : nullptr);
         }
     }
 }

@@ -399,8 +399,8 @@ int fjsp_mlp_train_step_values(int32_t mode, float *d_params, const float *d_x, 
 /* a_task ~ Categorical(softmax(task(state.float()))), then -- if machine_layers > 0 --
  * a_machine ~ Categorical(softmax(machine(cat(state.float(), a_task)))) for `rows` states f64[rows][state_size].
  * A network is Linear-ReLU-...-Linear: n linear layers (1..6), dims[n + 1] widths (each <= 256, outputs <= 64,
- * dims[0] = state_size, resp. state_size + 1), weights[l] f32[dims[l+1]][dims[l]] row-major and biases[l] device
- * pointers (torch.nn.Linear's own storage).  Randomness: a counter-based stream per row -- splitmix64(seed, row,
+ * dims[0] = state_size, resp. state_size + 1), weights[l] f32[dims[l]][dims[l+1]] row-major -- the TRANSPOSE of
+ * torch.nn.Linear.weight, so that the threads of a wave read consecutive words -- and biases[l] f32[dims[l+1]], device pointers.  Randomness: a counter-based stream per row -- splitmix64(seed, row,
  * d_draws[row]) -- whose draw counters u32[rows] live in device memory and advance with every call, so the launch can be
  * replayed from a HIP graph.  d_p_task / d_p_machine (nullable): the f32 probabilities the actions were drawn from.
  * Other shapes: FJSP_E_UNSUPPORTED (the caller keeps the library path). */
