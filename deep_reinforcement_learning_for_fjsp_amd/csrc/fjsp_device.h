@@ -99,6 +99,8 @@ struct Layout {
     // ... and the {arrival, rate} table once more MACHINE-major, f64[MP][64][2]: Machine.gap_ave reads whole machines, and in
     // large batches only the candidate ones (fjsp_group.hip g_gap_ave_lean: 5 lines per candidate instead of the whole table)
     uint32_t i_colm;
+    uint32_t i_op8;          // row-kernel batches: {stage | J_r | kind word, elig | fmask} of every operation type, 8 B each, contiguous
+                             // (the large-batch build's operation words: 40 types = 2.5 lines instead of the 5 of the 16-byte slots)
     // env record: EnvScalars at 0
     uint32_t e_stride;
     uint32_t e_tend;    // i32[MP]  machine.time_end

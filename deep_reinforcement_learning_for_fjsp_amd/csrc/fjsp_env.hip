@@ -408,6 +408,7 @@ int fjsp_env_create(const fjsp_instances *s, int32_t first, int32_t n_inst, int3
         }
         L.i_op = b.grp ? take(2048 + 128, 256) : 0u;
         L.i_colm = b.grp ? take(MP * 64 * 16, 128) : 0u;
+        L.i_op8 = b.grp ? take(64 * 8, 128) : 0u;
         L.i_stride = (uint32_t)((o + 255) / 256 * 256);
         o = 192;                                         // EnvScalars (144 B), padded
         L.e_tend = take(MP * 4, 4); L.e_mjob = take(MP * 4, 4); L.e_jst = take(JP * 4, 4); L.e_un = take(b.single_job ? 8 : MP * KP * 8, 8); L.e_asg = take(KP, 4);

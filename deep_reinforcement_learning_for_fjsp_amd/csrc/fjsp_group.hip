@@ -726,8 +726,14 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
         A[s] = make_uint4(0u, 0u, 0u, 0u); B[s] = make_double2(0.0, 0.0);
         if (16 * s + e.l < kq) {
             const unsigned char *slot = op + s * 512;
-            A[s] = reinterpret_cast<const uint4 *>(slot)[e.l];
-            if (EARLY) B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];      // (large batches: g_gather_current, g_observe)
+            if (EARLY) {
+                A[s] = reinterpret_cast<const uint4 *>(slot)[e.l];
+                B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];      // (large batches: g_gather_current, g_observe)
+            } else {
+                // large batches: the two words they use, from the 8-byte copy (the due date comes from the job's lane, g_observe)
+                const uint2 a8 = reinterpret_cast<const uint2 *>(ir + b.L.i_op8)[16 * s + e.l];
+                A[s] = make_uint4(a8.x, a8.y, 0u, 0u);
+            }
         }
     }
     const uint32_t asgw = reinterpret_cast<const uint32_t *>(er + FO::e_asg((uint32_t)MP, (uint32_t)JP, 64u, true))[e.l];
@@ -756,7 +762,7 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
     }
     if (!EARLY && !b.kenv_first && b.kmax > 48 && e.nslots > 3) {
         // more than 48 operation types in one of the wave's environments (rare at 10x5): one more round trip for the fourth slot
-        if (48 + e.l < e.K) A[3] = reinterpret_cast<const uint4 *>(op + 3 * 512)[e.l];
+        if (48 + e.l < e.K) { const uint2 a8 = reinterpret_cast<const uint2 *>(ir + b.L.i_op8)[48 + e.l]; A[3] = make_uint4(a8.x, a8.y, 0u, 0u); }
     }
 #pragma unroll
     for (int s = 0; s < GS; ++s) {

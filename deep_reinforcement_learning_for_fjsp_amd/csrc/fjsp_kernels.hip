@@ -1581,6 +1581,7 @@ __global__ void fluid_tables_kernel(DevBatch b) {
         // (the fourth word belongs to the host packer: slot 0, lane m = operation types machine m can process)
         uint32_t *a = reinterpret_cast<uint32_t *>(slot) + 4 * (k & 15);
         a[0] = kb; a[1] = (inst_ptr<const uint32_t>(b, inst, b.L.i_elig)[k] & 0xFFu) | (fm << 8); a[2] = (uint32_t)due;
+        inst_ptr<uint2>(b, inst, b.L.i_op8)[k] = make_uint2(a[0], a[1]);              // the same two words, 8 bytes apart (large-batch build)
         reinterpret_cast<double2 *>(slot + 256)[k & 15] = make_double2(valid ? s : 0.0, valid ? 1.0 / s : 0.0);
     }
 }
