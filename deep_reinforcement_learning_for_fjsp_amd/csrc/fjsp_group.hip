@@ -585,7 +585,7 @@ GDEV double g_observe(const GE<V> &e, const DevBatch &b, bool on, bool stats_onl
             const uint32_t kb = e.kB[s];
             const int kind = (int)((kb >> 16) & 0xFu);
             const uint32_t njk = greadu(e.jwl, kind, e.gb) & 0xFFu;
-            const int due_s = EARLY ? e.due[s] : gread(e.duej, kind, e.gb);       // (one job per kind: the type's due date is its job's)
+            const int due_s = gread(e.duej, kind, e.gb);                          // (one job per kind: the type's due date is its job's)
             in[s] = njk <= (kb & 0xFFu);
             const double de = (td + rt[s].y) - (double)due_s;
             const bool cnte = in[s] && de > 0.0;
@@ -726,14 +726,10 @@ GDEV void g_open(GE<V> &e, const DevBatch &b, int wave_id, unsigned char *lds, i
         A[s] = make_uint4(0u, 0u, 0u, 0u); B[s] = make_double2(0.0, 0.0);
         if (16 * s + e.l < kq) {
             const unsigned char *slot = op + s * 512;
-            if (EARLY) {
-                A[s] = reinterpret_cast<const uint4 *>(slot)[e.l];
-                B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];      // (large batches: g_gather_current, g_observe)
-            } else {
-                // large batches: the two words they use, from the 8-byte copy (the due date comes from the job's lane, g_observe)
-                const uint2 a8 = reinterpret_cast<const uint2 *>(ir + b.L.i_op8)[16 * s + e.l];
-                A[s] = make_uint4(a8.x, a8.y, 0u, 0u);
-            }
+            // the two operation words from the 8-byte copy (the due date comes from the job's lane, g_observe)
+            const uint2 a8 = reinterpret_cast<const uint2 *>(ir + b.L.i_op8)[16 * s + e.l];
+            A[s] = make_uint4(a8.x, a8.y, 0u, 0u);
+            if (EARLY) B[s] = reinterpret_cast<const double2 *>(slot + 256)[e.l];      // (large batches: g_gather_current, g_observe)
         }
     }
     const uint32_t asgw = reinterpret_cast<const uint32_t *>(er + FO::e_asg((uint32_t)MP, (uint32_t)JP, 64u, true))[e.l];
