@@ -92,7 +92,7 @@ SIGNATURES = {
     "fjsp_mlp_train_step_values": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, C.c_float, _vp, _i32, _vp, _vp, _vp, _vp, _vp,
                                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "fjsp_policy_sample": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
-    "fjsp_policy_pair_sample": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fjsp_policy_pair_sample": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
 }
 
 

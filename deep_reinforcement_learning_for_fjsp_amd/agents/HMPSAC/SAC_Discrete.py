@@ -179,24 +179,25 @@ class SAC_Discrete(Base_Agent, Config):
         return cache[key]
 
     @torch.no_grad()
-    def pick_lower_action(self, which, state):
-        """:277-284 for a batch: env e follows lower policy which[e] (a scalar means everyone)."""
+    def pick_lower_action(self, which, state, out=None):
+        """:277-284 for a batch: env e follows lower policy which[e] (a scalar means everyone).  out: u8[N, 2] to write into."""
         fused = state.is_cuda and state.dtype == torch.float64 and state.is_contiguous()
-        if fused and not torch.is_tensor(which):
-            sm = self._sampler(int(which))
-            if sm is not None:
-                a_t, a_m = sm.sample(state)
-                return torch.stack([a_t, a_m], 1).to(torch.uint8)
-        if fused and torch.is_tensor(which):
-            sms = {k: self._sampler(k) for k in self.policy_dict}
-            if all(v is not None for v in sms.values()):
-                a_t = torch.zeros(state.shape[0], dtype=torch.long, device=state.device)
-                a_m = torch.zeros_like(a_t)
-                for k, sm in sms.items():            # every lower policy proposes for every env, the controller's choice selects
-                    t, m = sm.sample(state)
-                    mine = which == k
-                    a_t, a_m = torch.where(mine, t, a_t), torch.where(mine, m, a_m)
-                return torch.stack([a_t, a_m], 1).to(torch.uint8)
+        if fused and (out is None or (out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (state.shape[0], 2))):
+            pair = out if out is not None else torch.empty(state.shape[0], 2, dtype=torch.uint8, device=state.device)
+            if not torch.is_tensor(which):
+                sm = self._sampler(int(which))
+                if sm is not None:
+                    sm.sample(state, pair_out=pair)           # the kernel writes the action pair itself
+                    return pair
+            elif which.dtype == torch.int64 and which.is_contiguous():
+                sms = {k: self._sampler(k) for k in self.policy_dict}
+                if all(v is not None for v in sms.values()):
+                    for k, sm in sms.items():            # every lower policy proposes for every env, the controller's choice selects
+                        sm.sample(state, pair_out=pair, select=which, which=int(k))
+                    return pair
+        if out is not None:
+            out.copy_(self.pick_lower_action(which, state))
+            return out
         s = state.float()
         sample = lambda nets, x: Categorical(nets(x), validate_args=False).sample()
         if not torch.is_tensor(which):
@@ -245,9 +246,9 @@ class SAC_Discrete(Base_Agent, Config):
             st["active"].copy_(st["done"] == 0)
             if which is None:
                 st["action"].copy_(self.pick_action(st["state"]))
-                st["pair"].copy_(self.pick_lower_action(st["action"], st["state"]))
+                self.pick_lower_action(st["action"], st["state"], out=st["pair"])
             else:
-                st["pair"].copy_(self.pick_lower_action(which, st["state"]))
+                self.pick_lower_action(which, st["state"], out=st["pair"])
 
         def store():
             if which is None:

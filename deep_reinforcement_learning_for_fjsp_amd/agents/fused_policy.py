@@ -96,12 +96,18 @@ class PolicyPairSampler:
         return d
 
     @torch.no_grad()
-    def sample(self, state, out_task=None, out_machine=None, probs=False):
+    def sample(self, state, out_task=None, out_machine=None, probs=False, pair_out=None, select=None, which=0):
         """state: f64[rows, S] contiguous on the networks' device.  Returns (a_task, a_machine) -- a_machine is None
-        without a machine network -- and, with probs=True, also the two probability tensors."""
+        without a machine network -- and, with probs=True, also the two probability tensors.  pair_out (u8[rows, 2],
+        contiguous): also receives (a_task, a_machine) in the environment's action encoding, for the rows with
+        select[row] == which (select: int64[rows]; None: every row)."""
         if state.dtype != torch.float64 or not state.is_contiguous() or state.device != self.device or state.dim() != 2 or state.shape[1] != self.S:
             raise ValueError("PolicyPairSampler.sample: state must be a contiguous f64[rows, %d] tensor on %s" % (self.S, self.device))
         rows = int(state.shape[0])
+        if pair_out is not None and (pair_out.dtype != torch.uint8 or tuple(pair_out.shape) != (rows, 2) or not pair_out.is_contiguous() or pair_out.device != self.device):
+            raise ValueError("PolicyPairSampler.sample: pair_out must be a contiguous u8[rows, 2] tensor on the networks' device")
+        if select is not None and (select.dtype != torch.int64 or select.numel() != rows or not select.is_contiguous() or select.device != self.device):
+            raise ValueError("PolicyPairSampler.sample: select must be a contiguous int64[rows] tensor on the networks' device")
         a_t = out_task if out_task is not None else torch.empty(rows, dtype=torch.int64, device=self.device)
         a_m = None
         if self.machine is not None:
@@ -118,7 +124,7 @@ class PolicyPairSampler:
                 self.task.n, self.task.dims.ctypes.data, C.addressof(self.task.w), C.addressof(self.task.b),
                 m.n if m else 0, m.dims.ctypes.data if m else None, C.addressof(m.w) if m else None, C.addressof(m.b) if m else None,
                 state.data_ptr(), rows, self.S, self.seed, self.draws(rows).data_ptr(), a_t.data_ptr(), ptr(a_m), ptr(p_t), ptr(p_m),
-                torch.cuda.current_stream(self.device).cuda_stream))
+                ptr(pair_out), ptr(select), int(which), torch.cuda.current_stream(self.device).cuda_stream))
         if probs:
             return a_t, a_m, p_t, p_m
         return a_t, a_m

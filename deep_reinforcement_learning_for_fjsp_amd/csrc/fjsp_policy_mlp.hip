@@ -45,6 +45,9 @@ struct PairArgs {
     unsigned int *draws;            // u32[rows]: draws made so far by each row's stream
     long long *a_task, *a_machine;  // i64[rows]
     float *p_task, *p_machine;      // nullable: f32[rows][outputs], the probabilities the samples were drawn from
+    unsigned char *pair;            // nullable: u8[rows][2] = (a_task, a_machine) in the environment's action encoding ...
+    const long long *select;        // ... written only where select[row] == which (nullable: everywhere)
+    int which;
 };
 
 // One network over the workgroup's rows: activations as [feature][kRows]; in = buf_a (first dims[0] features valid), the
@@ -160,7 +163,12 @@ __global__ __launch_bounds__(kWidth) void policy_pair_kernel(PairArgs a) {
         const int row = row0 + tid;
         if (row < a.rows) {
             const unsigned d = a.draws[row] - 1u;
-            a.a_machine[row] = softmax_sample(logits + tid, no_m, a.seed, (unsigned)row, d, a.p_machine ? a.p_machine + (size_t)row * no_m : nullptr);
+            const int pick_m = softmax_sample(logits + tid, no_m, a.seed, (unsigned)row, d, a.p_machine ? a.p_machine + (size_t)row * no_m : nullptr);
+            a.a_machine[row] = pick_m;
+            if (a.pair && (!a.select || a.select[row] == (long long)a.which)) {
+                a.pair[2 * row] = (unsigned char)s_task[tid];
+                a.pair[2 * row + 1] = (unsigned char)pick_m;
+            }
         }
     }
 }
@@ -188,7 +196,7 @@ extern "C" int fjsp_policy_pair_sample(int32_t task_layers, const int32_t *task_
                                        int32_t machine_layers, const int32_t *machine_dims, const float *const *machine_w,
                                        const float *const *machine_b, const double *d_state, int32_t rows, int32_t state_size, uint64_t seed,
                                        uint32_t *d_draws, int64_t *d_a_task, int64_t *d_a_machine, float *d_p_task, float *d_p_machine,
-                                       void *stream) {
+                                       uint8_t *d_pair, const int64_t *d_select, int32_t which, void *stream) {
     if (!d_state || !d_draws || !d_a_task || rows <= 0 || state_size < 1 || state_size >= kWidth || (machine_layers && !d_a_machine)) {
         fjsp::set_error("fjsp_policy_pair_sample: bad arguments"); return FJSP_E_ARG;
     }
@@ -201,6 +209,8 @@ extern "C" int fjsp_policy_pair_sample(int32_t task_layers, const int32_t *task_
     a.state = d_state; a.rows = rows; a.S = state_size; a.seed = seed; a.draws = d_draws;
     a.a_task = reinterpret_cast<long long *>(d_a_task); a.a_machine = reinterpret_cast<long long *>(d_a_machine);
     a.p_task = d_p_task; a.p_machine = d_p_machine;
+    if (d_pair && !machine_layers) { fjsp::set_error("fjsp_policy_pair_sample: d_pair needs the machine network"); return FJSP_E_ARG; }
+    a.pair = d_pair; a.select = reinterpret_cast<const long long *>(d_select); a.which = which;
     hipLaunchKernelGGL(policy_pair_kernel, dim3((unsigned)((rows + kRows - 1) / kRows)), dim3(kWidth), 0, (hipStream_t)stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fjsp::set_error(std::string("fjsp_policy_pair_sample: ") + hipGetErrorString(e)); return FJSP_E_HIP; }

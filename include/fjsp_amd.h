@@ -403,12 +403,15 @@ int fjsp_mlp_train_step_values(int32_t mode, float *d_params, const float *d_x, 
  * torch.nn.Linear.weight, so that the threads of a wave read consecutive words -- and biases[l] f32[dims[l+1]], device pointers.  Randomness: a counter-based stream per row -- splitmix64(seed, row,
  * d_draws[row]) -- whose draw counters u32[rows] live in device memory and advance with every call, so the launch can be
  * replayed from a HIP graph.  d_p_task / d_p_machine (nullable): the f32 probabilities the actions were drawn from.
+ * d_pair (nullable, needs the machine network): u8[rows][2] = (a_task, a_machine), the action pair as fjsp_env_step takes it,
+ * written for the rows with d_select[row] == which (d_select NULL: every row) -- pick_lower_action's "env e follows lower
+ * policy which[e]" without the gather / where launches around it.
  * Other shapes: FJSP_E_UNSUPPORTED (the caller keeps the library path). */
 int fjsp_policy_pair_sample(int32_t task_layers, const int32_t *task_dims, const float *const *task_w, const float *const *task_b,
                             int32_t machine_layers, const int32_t *machine_dims, const float *const *machine_w,
                             const float *const *machine_b, const double *d_state, int32_t rows, int32_t state_size, uint64_t seed,
                             uint32_t *d_draws, int64_t *d_a_task, int64_t *d_a_machine, float *d_p_task, float *d_p_machine,
-                            void *stream);
+                            uint8_t *d_pair, const int64_t *d_select, int32_t which, void *stream);
 
 #ifdef __cplusplus
 }

@@ -629,6 +629,18 @@ def test_one_launch_policy_pair_sampling(torch_gpu, rows, hidden, layers):
             counts.scatter_add_(1, t.unsqueeze(1), torch.ones(64, 1, device="cuda"))
         freq = counts / 200.0
         assert float((freq - want_t[:64]).abs().max()) < 0.15
+    # the action pair in the environment's encoding, written by the kernel itself; with `select` only the chosen rows
+    sm3 = fused_policy.PolicyPairSampler(task.layers_1, machine.layers_2, seed=1234)
+    pair = torch.full((rows, 2), 255, dtype=torch.uint8, device="cuda")
+    c_t, c_m = sm3.sample(state, pair_out=pair)
+    assert torch.equal(c_t, a_t) and torch.equal(c_m, a_m)                   # (same seed, same draw counters as the first call)
+    assert torch.equal(pair, torch.stack([a_t, a_m], 1).to(torch.uint8))
+    select = (torch.arange(rows, device="cuda") % 3).contiguous()
+    pair2 = torch.full((rows, 2), 255, dtype=torch.uint8, device="cuda")
+    d_t, d_m = sm3.sample(state, pair_out=pair2, select=select, which=1)
+    mine = select == 1
+    assert torch.equal(pair2[mine], torch.stack([d_t, d_m], 1).to(torch.uint8)[mine])
+    assert bool((pair2[~mine] == 255).all())
     # a network that does not fit is refused (the caller keeps the library path)
     wide = TaskPolicyNet(S, 300, 2, 12).cuda()
     assert not fused_policy.supported(wide.layers_1)
